@@ -1,0 +1,103 @@
+"""Loader for the C-ABI library declared in include/sde_hip.h.
+
+The product path has NO fallback: if libsde_hip.so is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "libsde_hip.so")
+MAX_CTX = 4
+F32, BF16 = 0, 1
+
+
+class SdeHipError(RuntimeError):
+    pass
+
+
+class PhotoDesc(Structure):
+    _fields_ = [("A", c_void_p), ("ctx", c_void_p * MAX_CTX), ("pose", c_void_p * MAX_CTX), ("depth", c_void_p), ("K", c_void_p),
+                ("B", c_int32), ("h", c_int32), ("w", c_int32), ("nctx", c_int32), ("automask", c_int32), ("reduce_mean", c_int32),
+                ("sx", c_float), ("sy", c_float), ("ssim_w", c_float), ("C1", c_float), ("C2", c_float)]
+
+
+_P, _I, _F = c_void_p, c_int, c_float
+_PROTOS = {
+    "sde_version": ([], c_int),
+    "sde_resize": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], c_int),
+    "sde_pose_vec2mat": ([_P, _P, _I, _P], c_int),
+    "sde_pose_vec2mat_bwd": ([_P, _P, _P, _I, _P], c_int),
+    "sde_view_synthesis": ([_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], c_int),
+    "sde_photo_num_blocks": ([_I, _I, _I, _I], c_int),
+    "sde_photo_fwd": ([POINTER(PhotoDesc), POINTER(c_void_p), _P, _P, _P, _P, _F, _I, _P], c_int),
+    "sde_photo_bwd": ([POINTER(PhotoDesc), POINTER(c_void_p), _P, _P, _F, _P, _I, _P, POINTER(c_void_p), _I, _P], c_int),
+    "sde_smooth_num_blocks": ([_I, _I, _I], c_int),
+    "sde_smooth_fwd": ([_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _F, _I, _P], c_int),
+    "sde_smooth_bwd": ([_P, _P, _P, _P, _P, _F, _I, _I, _I, _P, _I, _P], c_int),
+    "sde_silog_num_blocks": ([_I, _I, _I], c_int),
+    "sde_silog_fwd": ([_P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P], c_int),
+    "sde_silog_bwd": ([_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P, _I, _P], c_int),
+}
+
+_lib = None
+
+
+def register_protos(protos):
+    """Other binding modules (conv, norm, ...) add their prototypes here before first use."""
+    _PROTOS.update(protos)
+    if _lib is not None:
+        _bind(_lib, protos)
+
+
+def _bind(L, protos):
+    for name, (args, res) in protos.items():
+        fn = getattr(L, name)   # AttributeError => the .so does not export what the header declares: fail loudly
+        fn.argtypes = args
+        fn.restype = res
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdeHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C simpledepthestimation_amd/csrc). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.sde_last_error.restype = c_char_p
+        _bind(L, _PROTOS)
+        _lib = L
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise SdeHipError(f"{name} failed ({rc}): {lib().sde_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise SdeHipError("simpledepthestimation_amd ops need CUDA (HIP) tensors; there is no CPU fallback")
+    if not t.is_contiguous():
+        raise SdeHipError("non-contiguous tensor passed to a HIP op")
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr_array(tensors):
+    arr = (c_void_p * MAX_CTX)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else 0
+    return arr

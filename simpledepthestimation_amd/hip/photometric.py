@@ -1,0 +1,212 @@
+"""Autograd wrappers over the photometric-path entry points of libsde_hip.so (include/sde_hip.h).
+
+Each Function owns the tensors its backward needs; kernels never allocate.  Everything is enqueued on
+torch's current stream and never synchronises (hipGraph-capture safe).
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise L.SdeHipError(f"expected float32 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+def resize(image, size, mode="bilinear"):
+    """camera.py:L40-46 resize_img (no autograd: only images / ground truth are resized on this path)."""
+    image = _f32c(image)
+    B, C, H, W = image.shape
+    h, w = int(size[0]), int(size[1])
+    if (H, W) == (h, w):
+        return image
+    out = torch.empty(B, C, h, w, device=image.device, dtype=torch.float32)
+    L.check(L.lib().sde_resize(L.ptr(image), L.ptr(out), B * C, H, W, h, w, 0 if mode == "bilinear" else 1, L.stream()), "sde_resize")
+    return out
+
+
+def view_synthesis_raw(image_B, depth_A, K, pose, sx=1.0, sy=1.0, want_indices=True):
+    """camera.py:L166-202 forward only.  Returns dict(sampled, Z, grid, valid, fx, fy)."""
+    image_B, depth_A, K, pose = _f32c(image_B), _f32c(depth_A), _f32c(K), _f32c(pose)
+    B, C, H, W = image_B.shape
+    dev = image_B.device
+    out = {"sampled": torch.empty(B, C, H, W, device=dev), "Z": torch.empty(B, 1, H, W, device=dev),
+           "grid": torch.empty(B, H, W, 2, device=dev), "valid": torch.empty(B, 1, H, W, device=dev, dtype=torch.uint8)}
+    if want_indices:
+        out["fx"] = torch.empty(B, H, W, device=dev, dtype=torch.int32)
+        out["fy"] = torch.empty(B, H, W, device=dev, dtype=torch.int32)
+    L.check(L.lib().sde_view_synthesis(L.ptr(image_B), L.ptr(depth_A), L.ptr(K), L.ptr(pose), sx, sy, B, C, H, W, L.ptr(out["sampled"]),
+                                       L.ptr(out["Z"]), L.ptr(out["grid"]), L.ptr(out["valid"]), L.ptr(out.get("fx")), L.ptr(out.get("fy")),
+                                       L.stream()), "sde_view_synthesis")
+    return out
+
+
+class _PoseVec2Mat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vec):
+        vec = _f32c(vec)
+        n = vec.shape[0]
+        mat = torch.empty(n, 4, 4, device=vec.device)
+        L.check(L.lib().sde_pose_vec2mat(L.ptr(vec), L.ptr(mat), n, L.stream()), "sde_pose_vec2mat")
+        ctx.save_for_backward(vec)
+        return mat
+
+    @staticmethod
+    def backward(ctx, dmat):
+        (vec,) = ctx.saved_tensors
+        dvec = torch.empty_like(vec)
+        L.check(L.lib().sde_pose_vec2mat_bwd(L.ptr(vec), L.ptr(_f32c(dmat)), L.ptr(dvec), vec.shape[0], L.stream()), "sde_pose_vec2mat_bwd")
+        return dvec
+
+
+def pose_vec2mat(vec):
+    """pose_utils.py:L130-137."""
+    return _PoseVec2Mat.apply(vec)
+
+
+def _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean):
+    d = L.PhotoDesc()
+    B, _, h, w = depth.shape
+    d.A = A.data_ptr(); d.depth = depth.data_ptr(); d.K = K.data_ptr()
+    for j, (c, p) in enumerate(zip(ctxs, poses)):
+        d.ctx[j] = c.data_ptr(); d.pose[j] = p.data_ptr()
+    d.B, d.h, d.w, d.nctx = B, h, w, len(ctxs)
+    d.automask, d.reduce_mean = int(bool(automask)), int(bool(reduce_mean))
+    d.sx, d.sy, d.ssim_w, d.C1, d.C2 = sx, sy, ssim_w, C1, C2
+    return d
+
+
+class _PhotoScale(torch.autograd.Function):
+    """One scale of MonoDepth2's photometric loss (MonoDepth2.py:L78-101,L116-124): returns mean(reduced map)."""
+
+    @staticmethod
+    def forward(ctx, depth, K, A, sx, sy, ssim_w, C1, C2, automask, reduce_mean, nctx, *rest):
+        ctxs, poses = rest[:nctx], rest[nctx:]
+        depth, K, A = _f32c(depth), _f32c(K), _f32c(A)
+        ctxs = [_f32c(c) for c in ctxs]
+        poses = [_f32c(p) for p in poses]
+        B, _, h, w = depth.shape
+        dev = depth.device
+        lib = L.lib()
+        d = _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean)
+        sampled = [torch.empty(B, 3, h, w, device=dev) for _ in range(nctx)]
+        sel = torch.empty(B, h, w, device=dev, dtype=torch.uint8)
+        partial = torch.empty(lib.sde_photo_num_blocks(B, h, w, 0), device=dev)
+        loss = torch.empty((), device=dev)
+        L.check(lib.sde_photo_fwd(ctypes.byref(d), L.ptr_array(sampled), L.ptr(sel), None, L.ptr(partial), L.ptr(loss), 1.0, 0, L.stream()),
+                "sde_photo_fwd")
+        ctx.save_for_backward(depth, K, A, sel, *ctxs, *poses, *sampled)
+        ctx.cfg = (sx, sy, ssim_w, C1, C2, automask, reduce_mean, nctx)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        sx, sy, ssim_w, C1, C2, automask, reduce_mean, nctx = ctx.cfg
+        t = ctx.saved_tensors
+        depth, K, A, sel = t[:4]
+        ctxs, poses, sampled = t[4:4 + nctx], t[4 + nctx:4 + 2 * nctx], t[4 + 2 * nctx:4 + 3 * nctx]
+        B, _, h, w = depth.shape
+        dev = depth.device
+        lib = L.lib()
+        d = _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean)
+        d_depth = torch.empty_like(depth)
+        d_pose = [torch.empty(B, 4, 4, device=dev) for _ in range(nctx)]
+        pp = torch.empty(lib.sde_photo_num_blocks(B, h, w, 1) * nctx * 12, device=dev)
+        gout = _f32c(gout)
+        L.check(lib.sde_photo_bwd(ctypes.byref(d), L.ptr_array(sampled), L.ptr(sel), L.ptr(gout), 1.0, L.ptr(d_depth), 0, L.ptr(pp),
+                                  L.ptr_array(d_pose), 0, L.stream()), "sde_photo_bwd")
+        return (d_depth, None, None, None, None, None, None, None, None, None, None) + (None,) * nctx + tuple(d_pose)
+
+
+def photometric_scale_loss(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):
+    if reduce not in ("min", "mean"):
+        raise NotImplementedError(reduce)           # MonoDepth2.py:L121-122
+    return _PhotoScale.apply(depth, K, A, float(sx), float(sy), float(ssim_w), float(C1), float(C2), bool(automask), reduce == "mean",
+                             len(ctxs), *ctxs, *poses)
+
+
+def photometric_maps(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):
+    """Forward only, exposing the individual maps / sampled frames / arg-min (tests, debugging)."""
+    depth, K, A = _f32c(depth), _f32c(K), _f32c(A)
+    ctxs = [_f32c(c) for c in ctxs]; poses = [_f32c(p) for p in poses]
+    B, _, h, w = depth.shape
+    dev = depth.device
+    lib = L.lib()
+    nctx = len(ctxs)
+    d = _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce == "mean")
+    nmaps = 2 * nctx if automask else nctx
+    sampled = [torch.empty(B, 3, h, w, device=dev) for _ in range(nctx)]
+    sel = torch.empty(B, h, w, device=dev, dtype=torch.uint8)
+    maps = torch.empty(B, nmaps, h, w, device=dev)
+    partial = torch.empty(lib.sde_photo_num_blocks(B, h, w, 0), device=dev)
+    loss = torch.empty((), device=dev)
+    L.check(lib.sde_photo_fwd(ctypes.byref(d), L.ptr_array(sampled), L.ptr(sel), L.ptr(maps), L.ptr(partial), L.ptr(loss), 1.0, 0, L.stream()),
+            "sde_photo_fwd")
+    return {"loss": loss, "maps": maps, "sampled": sampled, "sel": sel}
+
+
+class _Smooth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, image):
+        depth, image = _f32c(depth), _f32c(image)
+        B, _, h, w = depth.shape
+        dev = depth.device
+        lib = L.lib()
+        nb = lib.sde_smooth_num_blocks(B, h, w)
+        mean_part = torch.empty(B * 32, device=dev)
+        dn = torch.empty(B, h, w, device=dev)
+        loss_part = torch.empty(nb, device=dev)
+        s_part = torch.empty(nb, device=dev)
+        loss = torch.empty((), device=dev)
+        L.check(lib.sde_smooth_fwd(L.ptr(depth), L.ptr(image), B, h, w, L.ptr(mean_part), L.ptr(dn), L.ptr(loss_part), L.ptr(s_part), L.ptr(loss),
+                                   1.0, 0, L.stream()), "sde_smooth_fwd")
+        ctx.save_for_backward(depth, dn, mean_part, s_part)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        depth, dn, mean_part, s_part = ctx.saved_tensors
+        B, _, h, w = depth.shape
+        d_depth = torch.empty_like(depth)
+        L.check(L.lib().sde_smooth_bwd(L.ptr(depth), L.ptr(dn), L.ptr(mean_part), L.ptr(s_part), L.ptr(_f32c(gout)), 1.0, B, h, w, L.ptr(d_depth),
+                                       0, L.stream()), "sde_smooth_bwd")
+        return d_depth, None
+
+
+def smoothness_loss(depth, image):
+    """smoothness_loss.py:L42-80."""
+    return _Smooth.apply(depth, image)
+
+
+class _Silog(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, est, gt, vf):
+        est, gt = _f32c(est), _f32c(gt)
+        B, _, h, w = est.shape
+        H, W = gt.shape[-2:]
+        dev = est.device
+        lib = L.lib()
+        part = torch.empty(lib.sde_silog_num_blocks(B, h, w) * 3, device=dev)
+        stats = torch.empty(4, device=dev)
+        L.check(lib.sde_silog_fwd(L.ptr(est), L.ptr(gt), B, h, w, H, W, vf, L.ptr(part), L.ptr(stats), L.stream()), "sde_silog_fwd")
+        ctx.save_for_backward(est, gt, stats)
+        ctx.vf = vf
+        return stats[3].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        est, gt, stats = ctx.saved_tensors
+        B, _, h, w = est.shape
+        H, W = gt.shape[-2:]
+        d_est = torch.empty_like(est)
+        L.check(L.lib().sde_silog_bwd(L.ptr(est), L.ptr(gt), L.ptr(stats), L.ptr(_f32c(gout)), 1.0, ctx.vf, B, h, w, H, W, L.ptr(d_est), 0,
+                                      L.stream()), "sde_silog_bwd")
+        return d_est, None, None
+
+
+def silog_loss(depth_est, depth_gt_full, variance_focus=0.85):
+    """losses.py:L10-13 applied to (pred, resize_img(gt, pred.shape, 'nearest')) -- Supervised.py:L44-45 -- in one kernel."""
+    return _Silog.apply(depth_est, depth_gt_full, float(variance_focus))
