@@ -101,6 +101,102 @@ int sde_silog_fwd(const float* est, const float* gt, int B, int h, int w, int H,
 int sde_silog_bwd(const float* est, const float* gt, const float* stats, const float* gout, float gscale, float variance_focus, int B, int h,
                   int w, int H, int W, float* d_est, int accumulate, sde_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Convolution engine (NHWC activations, fp32 or bf16 storage, fp32 accumulate)
+ * ------------------------------------------------------------------------------------------------- */
+#define SDE_SRC_PLAIN 0   /* input tensor as stored */
+#define SDE_SRC_UPCAT 1   /* cat(F.interpolate(x0, scale 2, nearest), x1) -- depth_decoder.py:L102-105 -- never materialised */
+#define SDE_SRC_ZEROINS 2 /* x0 with zeros inserted between pixels: data-gradient of a stride-2 convolution */
+#define SDE_ACT_NONE 0
+#define SDE_ACT_ELU 1
+#define SDE_ACT_RELU 2
+
+/* Input side of a convolution.  The virtual input is [Bn, IH, IW, C0+C1]; channel counts are multiples of 16 bytes. */
+typedef struct sde_conv_desc {
+    const void* x0; /* [Bn, H0, W0, C0] */
+    const void* x1; /* [Bn, IH, IW, C1] (SDE_SRC_UPCAT only) or NULL */
+    int32_t dtype;  /* SDE_F32 / SDE_BF16 (storage type of x0, x1, weights and outputs) */
+    int32_t C0, C1, H0, W0, IH, IW, src_mode;
+    int32_t KH, KW, stride, pad;
+    int32_t reflect; /* 1: ReflectionPad2d(pad) (depth_decoder.py:L40-43), 0: zero padding */
+    int32_t Bn, OH, OW;
+} sde_conv_desc;
+
+/* master fp32 OIHW weight [Cout,Cin,KH,KW] -> K-major operand in `dtype`:
+ *   for_dgrad = 0: [Cout_pad][KH][KW][Cin_pad]            (forward and weight-gradient layout)
+ *   for_dgrad = 1: [Cin_pad][KH][KW][Cout_pad], taps flipped (data-gradient operand) */
+int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cin_pad, int Cout_pad, int for_dgrad,
+                    sde_stream_t stream);
+
+/* y[Bn,OH,OW,ldy] = act(conv(virtual input, w_packed) + bias); channels >= Cout of y are written as zeros.
+ * Replaces nn.Conv2d (+ReflectionPad2d, +upsample/cat, +nn.ELU) forward -- resnet_encoder.py:L91-97, depth_decoder.py:L21-53,
+ * PoseNet.py:L13-16 -- and, with the flipped operand of sde_pack_weight(for_dgrad=1), their data-gradient.
+ * stats (optional): [sde_conv_fwd_tiles_m][Cout][2] per-tile (sum, sum of squares) of the stored outputs, for BatchNorm. */
+int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
+                 sde_stream_t stream);
+int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy);
+
+/* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).
+ * slab: caller workspace [splits][Cout][KH*KW*(C0+C1)] fp32, splits = sde_conv_wgrad_splits(d, Cout). */
+int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout);
+int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, int Cin_real, float* slab, int splits, float* dw, int accumulate,
+                   sde_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Layers around the convolutions (NHWC, `dtype` storage, fp32 math)
+ * ------------------------------------------------------------------------------------------------- */
+/* (img - mean)/std (Supervised.py:L39, MonoDepth2.py:L60) fused with NCHW fp32 -> NHWC `dtype`, channel padding and the optional
+ * torch.flip(image,[3]) of DepthResNet.py:L52-53.  mean/std may both be NULL (PoseNet input: no normalisation). */
+int sde_prep_input(const float* img, const float* mean, const float* std_, int B, int C, int H, int W, int Cpad, int flip, int dtype, void* out,
+                   sde_stream_t stream);
+
+/* Training-mode nn.BatchNorm2d of torchvision's ResNet (resnet_encoder.py:L92, blocks L94-97): batch statistics from the
+ * convolution's stats slab -> bnp [4][C] = (mean, rstd, scale, shift); running stats updated in place (momentum, unbiased var). */
+int sde_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* bnp, sde_stream_t stream);
+int sde_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C, float* bnp,
+                       sde_stream_t stream);
+/* out = [relu](y*scale + shift [+ residual]) */
+int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu, long M, int C, int dtype, void* out, sde_stream_t stream);
+/* BatchNorm(+ReLU, +residual) backward.  part: [sde_reduce_num_blocks(M)][C][2] workspace, coef: [2][C] workspace.
+ * dy [M,C]; dres (optional) [M,C] = gradient of the residual input; dgamma/dbeta [C] (+)=. */
+int sde_reduce_num_blocks(long M);
+int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, const float* gamma, int relu, long M, int C, int dtype, float* part,
+               float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dy, void* dres, sde_stream_t stream);
+
+/* nn.MaxPool2d(3, 2, 1) (resnet_encoder.py:L94).  idx: [B,OH,OW,C] u8 arg-max saved for backward. */
+int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* out, uint8_t* idx, sde_stream_t stream);
+int sde_maxpool_bwd(const void* dout, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream);
+
+/* dz = dout * act'(out) (nn.ELU / nn.ReLU backward) fused with the bias gradient dbias[c] (+)= sum_rows dz[:, c], c < Cbias.
+ * dz and/or dbias may be NULL; part: [sde_reduce_num_blocks(M)][C] workspace (needed when dbias != NULL). */
+int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias, int accumulate,
+                     sde_stream_t stream);
+
+/* Backward of ReflectionPad2d(1) [+ nearest x2 upsample + channel concat] (depth_decoder.py:L40-47,L102-105):
+ * dxp [B,H+2,W+2,C] (gradient w.r.t. the padded virtual input, from the data-gradient GEMM) ->
+ * upcat=0: dx0 [B,H,W,C];  upcat=1: dx0 [B,H/2,W/2,C0], dx1 [B,H,W,C-C0]. */
+int sde_refl_fold(const void* dxp, int B, int H, int W, int C, int C0, int upcat, int dtype, void* dx0, void* dx1, sde_stream_t stream);
+
+/* nn.Softplus + disp_to_depth(min_depth, max_depth)[1] (+ torch.flip of the output) -- depth_decoder.py:L9-18,L108, DepthResNet.py:L57-60.
+ * y [B,H,W,ld] (channel 0 is the disparity logit) -> depth [B,1,H,W] fp32; backward writes dy [B,H,W,ld] (channels > 0 zero). */
+int sde_depth_head_fwd(const void* y, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, float* depth, sde_stream_t stream);
+int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, void* dy,
+                       sde_stream_t stream);
+
+/* nn.GroupNorm(G) + nn.ReLU (PoseNet.py:L13-20).  part: [B][16][C][2] workspace, gnp: [B][G][2] (mean, rstd) saved for backward,
+ * coef: [B][G][2] workspace. */
+int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype, float* part, float* gnp,
+                    void* out, sde_stream_t stream);
+int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,
+                    float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream);
+
+/* torch.optim.Adam / AdamW step (projects/MonoDepth2/train.py:L50-57, projects/Supervised/train.py:L77-81) over ONE flat fp32 buffer.
+ * Segment s covers [seg_end[s-1], seg_end[s]) with its own lr / weight decay (device arrays, so a captured graph sees updates);
+ * bias_corr = device [2] = (1 - beta1^t, 1 - beta2^t); grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
+                  float beta2, float eps, const float* bias_corr, float grad_scale, int decoupled_wd, sde_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

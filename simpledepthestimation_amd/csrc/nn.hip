@@ -1,0 +1,851 @@
+// Bandwidth-bound layers around the convolution GEMMs (gfx950): input normalisation + layout change, training-mode
+// BatchNorm (+ReLU, +residual) forward/backward, GroupNorm+ReLU, 3x3/2 max-pool, activation backward + bias gradient,
+// reflection-pad / nearest-upsample gradient folding, the depth head (softplus + disp_to_depth) and fused Adam/AdamW.
+//
+// Replaces (reference, read-only): (img-mean)/std of meta_arch/Supervised.py:L39 / MonoDepth2.py:L60; torchvision's
+// BatchNorm2d/ReLU/MaxPool2d/residual add inside layers/resnet_encoder.py:L91-97; nn.ELU, ReflectionPad2d backward,
+// F.interpolate(nearest) backward and torch.cat backward of layers/depth_decoder.py:L21-53,L95-110; nn.Softplus +
+// disp_to_depth (depth_decoder.py:L9-18, DepthResNet.py:L57) and torch.flip (DepthResNet.py:L52-60); nn.GroupNorm(16)+ReLU
+// of pose_net/PoseNet.py:L13-20; torch.optim.Adam / AdamW of projects/*/train.py.
+//
+// Layout: activations NHWC, 16-byte channel groups; every kernel moves 16 B per lane per access with lanes running along
+// the channel-fastest axis (full 1 KiB per wave instruction).  Channel reductions write per-workgroup partial slabs that a
+// small second kernel sums in fixed order (fp64) -- no float atomics, bit-reproducible statistics and gradients.
+#include "common.h"
+#include "sde_hip.h"
+
+namespace {
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int V = 4; };
+template <> struct VecOf<bf16_t> { static constexpr int V = 8; };
+
+template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* v);
+template <> __device__ __forceinline__ void load_vec<float>(const float* p, float* v) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, float* v) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* v);
+template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const float* v) {
+    bf16_t o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+    *reinterpret_cast<uint4*>(p) = *reinterpret_cast<uint4*>(o);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input: NCHW fp32 image -> normalised NHWC T, channels zero-padded to Cpad, optional horizontal flip
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) prep_input_kernel(const float* __restrict__ img, const float* __restrict__ mean, const float* __restrict__ std_,
+                                                         int B, int C, int H, int W, int Cpad, int flip, T* __restrict__ out) {
+    const long n = (long)B * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+        const int xs = flip ? W - 1 - x : x;
+        T* o = out + i * Cpad;
+        for (int c = 0; c < Cpad; ++c) {
+            float v = 0.f;
+            if (c < C) {
+                v = img[(((long)b * C + c) * H + y) * W + xs];
+                if (mean) v = (v - mean[c]) / std_[c];
+            }
+            o[c] = (T)v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BatchNorm
+// ------------------------------------------------------------------------------------------------------------------
+// bnp layout: [4][C] = mean, rstd, scale (= gamma*rstd), shift (= beta - mean*scale)
+__global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict__ part, int tiles, int C, float count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                         float momentum, float eps, float* __restrict__ bnp) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int t = 0; t < tiles; ++t) { s1 += part[((size_t)t * C + c) * 2]; s2 += part[((size_t)t * C + c) * 2 + 1]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    bnp[c] = (float)mean; bnp[C + c] = rstd; bnp[2 * C + c] = sc; bnp[3 * C + c] = beta[c] - (float)mean * sc;
+    if (rmean) {   // running statistics: unbiased variance, torch momentum convention
+        const double unb = count > 1.f ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void __launch_bounds__(64) bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
+                                                            float* __restrict__ bnp) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.0f / sqrtf(rvar[c] + eps);
+    const float sc = gamma[c] * rstd;
+    bnp[c] = rmean[c]; bnp[C + c] = rstd; bnp[2 * C + c] = sc; bnp[3 * C + c] = beta[c] - rmean[c] * sc;
+}
+
+// out = act(y*scale + shift (+ residual))
+template <typename T>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ bnp, const T* __restrict__ res, int relu,
+                                                       long M, int C, T* __restrict__ out) {
+    constexpr int V = VecOf<T>::V;
+    const int cch = C / V;
+    const long total = M * cch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cch) * V;
+        float v[V], r[V];
+        load_vec<T>(y + i * V, v);
+        if (res) load_vec<T>(res + i * V, r);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = v[e] * bnp[2 * C + c0 + e] + bnp[3 * C + c0 + e];
+            if (res) t += r[e];
+            if (relu) t = fmaxf(t, 0.f);
+            v[e] = t;
+        }
+        store_vec<T>(out + i * V, v);
+    }
+}
+
+// Channel reduction pass of BN backward: partial[blk][C][2] = (sum dz, sum dz*xhat), dz = dout * (out > 0 if relu)
+constexpr int RED_ROWS = 8;   // a 256-thread block = (C/V chunk columns) x rows; here handled generically below
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y,
+                                                            const float* __restrict__ bnp, int relu, long M, int C, long rows_per_block,
+                                                            float* __restrict__ part) {
+    constexpr int V = VecOf<T>::V;
+    extern __shared__ float sh[];   // [2][C] accumulators shared by the block
+    const int cch = C / V;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    // thread -> fixed chunk column when cch divides 256 or vice versa; general case handled by striding over (row, chunk)
+    const long total = (r1 - r0) * cch;
+    if (cch <= 256 && 256 % cch == 0) {
+        const int col = threadIdx.x % cch, c0 = col * V;
+        const int rstep = 256 / cch;
+        float a1[V], a2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+        for (long r = r0 + threadIdx.x / cch; r < r1; r += rstep) {
+            const long off = (r * cch + col) * V;
+            float d[V], o[V], yv[V];
+            load_vec<T>(dout + off, d);
+            if (relu) load_vec<T>(out + off, o);
+            load_vec<T>(y + off, yv);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float dz = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+                const float xh = (yv[e] - bnp[c0 + e]) * bnp[C + c0 + e];
+                a1[e] += dz; a2[e] += dz * xh;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) { atomicAdd(&sh[c0 + e], a1[e]); atomicAdd(&sh[C + c0 + e], a2[e]); }
+    } else {
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const int col = (int)(i % cch), c0 = col * V;
+            const long off = (r0 * cch + i) * V;
+            float d[V], o[V], yv[V];
+            load_vec<T>(dout + off, d);
+            if (relu) load_vec<T>(out + off, o);
+            load_vec<T>(y + off, yv);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float dz = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+                const float xh = (yv[e] - bnp[c0 + e]) * bnp[C + c0 + e];
+                atomicAdd(&sh[c0 + e], dz); atomicAdd(&sh[C + c0 + e], dz * xh);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+        part[((size_t)blockIdx.x * C + i) * 2] = sh[i];
+        part[((size_t)blockIdx.x * C + i) * 2 + 1] = sh[C + i];
+    }
+}
+
+// coef layout [2][C]: mean(dz), mean(dz*xhat); also dgamma (+)=, dbeta (+)=
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float count, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int t = 0; t < nblk; ++t) { s1 += part[((size_t)t * C + c) * 2]; s2 += part[((size_t)t * C + c) * 2 + 1]; }
+    coef[c] = (float)(s1 / count); coef[C + c] = (float)(s2 / count);
+    dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+    dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+}
+
+// dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat));  d_res = dz (optional)
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y,
+                                                           const float* __restrict__ bnp, const float* __restrict__ coef, int relu, long M, int C,
+                                                           T* __restrict__ dy, T* __restrict__ dres) {
+    constexpr int V = VecOf<T>::V;
+    const int cch = C / V;
+    const long total = M * cch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cch) * V;
+        float d[V], o[V], yv[V], g[V];
+        load_vec<T>(dout + i * V, d);
+        if (relu) load_vec<T>(out + i * V, o);
+        load_vec<T>(y + i * V, yv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float dz = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+            const float xh = (yv[e] - bnp[c0 + e]) * bnp[C + c0 + e];
+            g[e] = bnp[2 * C + c0 + e] * (dz - coef[c0 + e] - xh * coef[C + c0 + e]);
+            d[e] = dz;
+        }
+        store_vec<T>(dy + i * V, g);
+        if (dres) store_vec<T>(dres + i * V, d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-2 pad-1 max-pool (NHWC) with saved arg-max (first maximum in row-major window order, like ATen)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ x, int B, int H, int W, int C, int OH, int OW, T* __restrict__ out,
+                                                          uint8_t* __restrict__ idx) {
+    constexpr int V = VecOf<T>::V;
+    const int cch = C / V;
+    const long total = (long)B * OH * OW * cch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % cch);
+        const long pix = i / cch;
+        const int ow = (int)(pix % OW), oh = (int)((pix / OW) % OH), b = (int)(pix / ((long)OW * OH));
+        float best[V]; int bi[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if (iw < 0 || iw >= W) continue;
+                float v[V];
+                load_vec<T>(x + (((long)b * H + ih) * W + iw) * C + col * V, v);
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
+            }
+        }
+        store_vec<T>(out + i * V, best);
+        uint8_t* ip = idx + i * V;
+#pragma unroll
+        for (int e = 0; e < V; ++e) ip[e] = (uint8_t)bi[e];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx, int B, int H, int W, int C, int OH,
+                                                          int OW, T* __restrict__ dx) {
+    constexpr int V = VecOf<T>::V;
+    const int cch = C / V;
+    const long total = (long)B * H * W * cch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % cch);
+        const long pix = i / cch;
+        const int iw = (int)(pix % W), ih = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = 0.f;
+        // windows (oh, ow) with ih = 2*oh - 1 + kh  =>  oh = (ih + 1 - kh)/2
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = ih + 1 - kh;
+            if (t < 0 || (t & 1)) continue;
+            const int oh = t >> 1;
+            if (oh >= OH) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int u = iw + 1 - kw;
+                if (u < 0 || (u & 1)) continue;
+                const int ow = u >> 1;
+                if (ow >= OW) continue;
+                const long o = ((((long)b * OH + oh) * OW + ow) * cch + col) * V;
+                float d[V];
+                load_vec<T>(dout + o, d);
+                const uint8_t* ip = idx + o;
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (ip[e] == kh * 3 + kw) g[e] += d[e];
+            }
+        }
+        store_vec<T>(dx + i * V, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Activation backward fused with the bias-gradient column sums: dz = dout * act'(out); partial[blk][C] = sum_rows dz
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__ dout, const T* __restrict__ out, int act, long M, int C,
+                                                           long rows_per_block, T* __restrict__ dz, float* __restrict__ part) {
+    constexpr int V = VecOf<T>::V;
+    extern __shared__ float sh[];   // [C]
+    const int cch = C / V;
+    if (part) {
+        for (int i = threadIdx.x; i < C; i += 256) sh[i] = 0.f;
+        __syncthreads();
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const long total = (r1 - r0) * cch;
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int c0 = (int)(i % cch) * V;
+        const long off = (r0 * cch + i) * V;
+        float d[V], o[V];
+        load_vec<T>(dout + off, d);
+        if (act != SDE_ACT_NONE) {
+            load_vec<T>(out + off, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if (act == SDE_ACT_ELU) d[e] = o[e] > 0.f ? d[e] : d[e] * (o[e] + 1.0f);     // ELU'(x) = exp(x) = out + 1 for x <= 0
+                else if (act == SDE_ACT_RELU) d[e] = o[e] > 0.f ? d[e] : 0.f;
+            }
+        }
+        if (dz) store_vec<T>(dz + off, d);
+        if (part) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) atomicAdd(&sh[c0 + e], d[e]);
+        }
+    }
+    if (part) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) part[(size_t)blockIdx.x * C + i] = sh[i];
+    }
+}
+
+__global__ void __launch_bounds__(64) colsum_finalize_kernel(const float* __restrict__ part, int nblk, int ld, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int t = 0; t < nblk; ++t) s += part[(size_t)t * ld + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gradient folding for the decoder: reflection pad backward (+ nearest x2 upsample backward + concat split)
+//   dxp [B, H+2, W+2, C] is the gradient w.r.t. the reflection-PADDED virtual input (what the data-gradient GEMM emits).
+//   plain : dx0 [B,H,W,C]            = fold(dxp)
+//   upcat : dx0 [B,H/2,W/2,C0]       = sum over the 2x2 upsampled block of fold(dxp)[..., :C0]
+//           dx1 [B,H,W,C1]           = fold(dxp)[..., C0:]
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void fold_at(const T* __restrict__ dxp, int b, int h, int w, int H, int W, int C, int c0, float* g) {
+    constexpr int V = VecOf<T>::V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] = 0.f;
+    // padded rows that ReflectionPad2d(1) maps onto row h: h+1 always, 0 if h == 1, H+1 if h == H-2 (both when H == 3)
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + 1;
+    if (h == 1) hs[nh++] = 0;
+    if (h == H - 2) hs[nh++] = H + 1;
+    ws[nw++] = w + 1;
+    if (w == 1) ws[nw++] = 0;
+    if (w == W - 2) ws[nw++] = W + 1;
+    for (int a = 0; a < nh; ++a)
+        for (int bb = 0; bb < nw; ++bb) {
+            float v[V];
+            load_vec<T>(dxp + (((long)b * (H + 2) + hs[a]) * (W + 2) + ws[bb]) * C + c0, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) g[e] += v[e];
+        }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) refl_fold_kernel(const T* __restrict__ dxp, int B, int H, int W, int C, int C0, int upcat, T* __restrict__ dx0,
+                                                        T* __restrict__ dx1) {
+    constexpr int V = VecOf<T>::V;
+    if (!upcat) {
+        const int cch = C / V;
+        const long total = (long)B * H * W * cch;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int col = (int)(i % cch);
+            const long pix = i / cch;
+            const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+            float g[V];
+            fold_at<T>(dxp, b, h, w, H, W, C, col * V, g);
+            store_vec<T>(dx0 + i * V, g);
+        }
+        return;
+    }
+    const int C1 = C - C0;
+    const int c0ch = C0 / V, c1ch = C1 / V;
+    const int H2 = H / 2, W2 = W / 2;
+    const long n0 = (long)B * H2 * W2 * c0ch, n1 = (long)B * H * W * c1ch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n0 + n1; i += (long)gridDim.x * 256) {
+        if (i < n0) {
+            const int col = (int)(i % c0ch);
+            const long pix = i / c0ch;
+            const int w = (int)(pix % W2), h = (int)((pix / W2) % H2), b = (int)(pix / ((long)W2 * H2));
+            float acc[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    float g[V];
+                    fold_at<T>(dxp, b, 2 * h + a, 2 * w + bb, H, W, C, col * V, g);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += g[e];
+                }
+            store_vec<T>(dx0 + i * V, acc);
+        } else {
+            const long j = i - n0;
+            const int col = (int)(j % c1ch);
+            const long pix = j / c1ch;
+            const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+            float g[V];
+            fold_at<T>(dxp, b, h, w, H, W, C, C0 + col * V, g);
+            store_vec<T>(dx1 + j * V, g);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Depth head tail: depth = 1 / (min_disp + (max_disp - min_disp) * softplus(y[..., 0])), optional horizontal flip
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) depth_head_fwd_kernel(const T* __restrict__ y, int B, int H, int W, int ld, float min_disp, float max_disp, int flip,
+                                                             float* __restrict__ depth) {
+    const long n = (long)B * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = (float)y[i * ld];
+        const float sp = v > 20.f ? v : log1pf(expf(v));
+        const float sd = min_disp + (max_disp - min_disp) * sp;
+        long o = i;
+        if (flip) { const int x = (int)(i % W); o = i - x + (W - 1 - x); }
+        depth[o] = 1.0f / sd;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) depth_head_bwd_kernel(const T* __restrict__ y, const float* __restrict__ ddepth, int B, int H, int W, int ld,
+                                                             float min_disp, float max_disp, int flip, T* __restrict__ dy) {
+    const long n = (long)B * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = (float)y[i * ld];
+        const float sp = v > 20.f ? v : log1pf(expf(v));
+        const float sd = min_disp + (max_disp - min_disp) * sp;
+        const float dsp = v > 20.f ? 1.f : 1.0f / (1.0f + expf(-v));
+        long o = i;
+        if (flip) { const int x = (int)(i % W); o = i - x + (W - 1 - x); }
+        const float g = ddepth[o] * (-1.0f / (sd * sd)) * (max_disp - min_disp) * dsp;
+        T* d = dy + i * ld;
+        d[0] = (T)g;
+        for (int c = 1; c < ld; ++c) d[c] = (T)0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupNorm(G) + ReLU, NHWC.  Stage 1: per (sample, chunk-of-pixels) per-channel (sum, sum^2) partials.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GN_CHUNKS = 16;
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ part /*[B][GN_CHUNKS][C][2]*/) {
+    extern __shared__ float sh[];   // [2][C]
+    const int b = blockIdx.y, ch = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    const int per = (HW + GN_CHUNKS - 1) / GN_CHUNKS;
+    const int p0 = ch * per, p1 = min(HW, p0 + per);
+    const long total = (long)(p1 - p0) * C;
+    const T* base = x + ((long)b * HW + p0) * C;
+    float a1 = 0.f, a2 = 0.f;
+    // thread walks elements with a fixed channel when 256 % C == 0 (C <= 256), else falls back to shared atomics per element
+    if (256 % C == 0) {
+        const int c = threadIdx.x % C;
+        for (long i = threadIdx.x; i < total; i += 256) { const float v = (float)base[i]; a1 += v; a2 += v * v; }
+        atomicAdd(&sh[c], a1); atomicAdd(&sh[C + c], a2);
+    } else {
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const int c = (int)(i % C);
+            const float v = (float)base[i];
+            atomicAdd(&sh[c], v); atomicAdd(&sh[C + c], v * v);
+        }
+    }
+    __syncthreads();
+    float* o = part + (((size_t)b * GN_CHUNKS + ch) * C) * 2;
+    for (int i = threadIdx.x; i < C; i += 256) { o[i * 2] = sh[i]; o[i * 2 + 1] = sh[C + i]; }
+}
+
+// gnp [B][G][2] = mean, rstd
+__global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict__ part, int B, int C, int G, int HW, float eps, float* __restrict__ gnp) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, gidx = i % G, cpg = C / G;
+    double s1 = 0, s2 = 0;
+    for (int ch = 0; ch < GN_CHUNKS; ++ch)
+        for (int c = gidx * cpg; c < (gidx + 1) * cpg; ++c) {
+            s1 += part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2];
+            s2 += part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2 + 1];
+        }
+    const double n = (double)HW * cpg, mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0) var = 0;
+    gnp[i * 2] = (float)mean;
+    gnp[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ gnp, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int B, int HW, int C, int G, int relu, T* __restrict__ out) {
+    const long total = (long)B * HW * C;
+    const int cpg = C / G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
+        const float* st = gnp + ((size_t)b * G + c / cpg) * 2;
+        float v = ((float)x[i] - st[0]) * st[1] * gamma[c] + beta[c];
+        if (relu) v = fmaxf(v, 0.f);
+        out[i] = (T)v;
+    }
+}
+
+// backward stage 1: per (sample, chunk) per-channel partial sums of dz and dz*xhat (dz = dout * relu mask)
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
+                                                           const float* __restrict__ gnp, int HW, int C, int G, int relu,
+                                                           float* __restrict__ part /*[B][GN_CHUNKS][C][2]*/) {
+    extern __shared__ float sh[];
+    const int b = blockIdx.y, ch = blockIdx.x, cpg = C / G;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    const int per = (HW + GN_CHUNKS - 1) / GN_CHUNKS;
+    const int p0 = ch * per, p1 = min(HW, p0 + per);
+    const long total = (long)(p1 - p0) * C;
+    const long base = ((long)b * HW + p0) * C;
+    if (256 % C == 0) {
+        const int c = threadIdx.x % C;
+        const float* st = gnp + ((size_t)b * G + c / cpg) * 2;
+        float a1 = 0.f, a2 = 0.f;
+        for (long i = threadIdx.x; i < total; i += 256) {
+            float d = (float)dout[base + i];
+            if (relu && !((float)out[base + i] > 0.f)) d = 0.f;
+            const float xh = ((float)x[base + i] - st[0]) * st[1];
+            a1 += d; a2 += d * xh;
+        }
+        atomicAdd(&sh[c], a1); atomicAdd(&sh[C + c], a2);
+    } else {
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const int c = (int)(i % C);
+            const float* st = gnp + ((size_t)b * G + c / cpg) * 2;
+            float d = (float)dout[base + i];
+            if (relu && !((float)out[base + i] > 0.f)) d = 0.f;
+            const float xh = ((float)x[base + i] - st[0]) * st[1];
+            atomicAdd(&sh[c], d); atomicAdd(&sh[C + c], d * xh);
+        }
+    }
+    __syncthreads();
+    float* o = part + (((size_t)b * GN_CHUNKS + ch) * C) * 2;
+    for (int i = threadIdx.x; i < C; i += 256) { o[i * 2] = sh[i]; o[i * 2 + 1] = sh[C + i]; }
+}
+
+// per (b, g): m1 = mean_g(gamma*dz), m2 = mean_g(gamma*dz*xhat); per channel: dgamma = sum_b sum dz*xhat, dbeta = sum_b sum dz
+__global__ void __launch_bounds__(64) gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int B, int C, int G, int HW,
+                                                             float* __restrict__ coef /*[B][G][2]*/, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int cpg = C / G;
+    if (i < B * G) {
+        const int b = i / G, gidx = i % G;
+        double s1 = 0, s2 = 0;
+        for (int ch = 0; ch < GN_CHUNKS; ++ch)
+            for (int c = gidx * cpg; c < (gidx + 1) * cpg; ++c) {
+                s1 += (double)gamma[c] * part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2];
+                s2 += (double)gamma[c] * part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2 + 1];
+            }
+        const double n = (double)HW * cpg;
+        coef[i * 2] = (float)(s1 / n); coef[i * 2 + 1] = (float)(s2 / n);
+    }
+    if (i < C) {
+        double s1 = 0, s2 = 0;
+        for (int b = 0; b < B; ++b)
+            for (int ch = 0; ch < GN_CHUNKS; ++ch) {
+                s1 += part[(((size_t)b * GN_CHUNKS + ch) * C + i) * 2];
+                s2 += part[(((size_t)b * GN_CHUNKS + ch) * C + i) * 2 + 1];
+            }
+        dgamma[i] = accumulate ? dgamma[i] + (float)s2 : (float)s2;
+        dbeta[i] = accumulate ? dbeta[i] + (float)s1 : (float)s1;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
+                                                           const float* __restrict__ gnp, const float* __restrict__ coef, const float* __restrict__ gamma,
+                                                           int B, int HW, int C, int G, int relu, T* __restrict__ dx) {
+    const long total = (long)B * HW * C;
+    const int cpg = C / G;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
+        const size_t gi = ((size_t)b * G + c / cpg) * 2;
+        float d = (float)dout[i];
+        if (relu && !((float)out[i] > 0.f)) d = 0.f;
+        const float xh = ((float)x[i] - gnp[gi]) * gnp[gi + 1];
+        dx[i] = (T)(gnp[gi + 1] * (gamma[c] * d - coef[gi] - xh * coef[gi + 1]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused Adam / AdamW over a flat fp32 parameter buffer split into segments with their own lr / weight decay
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                                   const long* __restrict__ seg_end, const float* __restrict__ seg_lr, const float* __restrict__ seg_wd, int nseg,
+                                                   float beta1, float beta2, float eps, const float* __restrict__ bias_corr /*[2]: 1-b1^t, 1-b2^t*/,
+                                                   float grad_scale, int decoupled) {
+    const float bc1 = bias_corr[0], bc2 = bias_corr[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        int s = 0;
+        while (s < nseg - 1 && i >= seg_end[s]) ++s;
+        const float lr = seg_lr[s], wd = seg_wd[s];
+        float gi = g[i] * grad_scale, pi = p[i];
+        if (decoupled) pi *= (1.0f - lr * wd);          // AdamW: torch.optim.AdamW
+        else gi += wd * pi;                             // Adam with L2 (wd = 0 on this path)
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+int grid_for(long n_items) {
+    long nb = (n_items + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 8192) nb = 8192;
+    return (int)nb;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+    do {                                       \
+        if ((dtype) == SDE_BF16) { CALL_BF16; } \
+        else { CALL_F32; }                     \
+    } while (0)
+
+extern "C" {
+
+int sde_prep_input(const float* img, const float* mean, const float* std_, int B, int C, int H, int W, int Cpad, int flip, int dtype, void* out,
+                   sde_stream_t stream) {
+    SDE_CHECK_ARG(img && out && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "sde_prep_input: bad argument");
+    SDE_CHECK_ARG((mean == nullptr) == (std_ == nullptr), "sde_prep_input: mean/std must both be given or both be null");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = grid_for((long)B * H * W);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(prep_input_kernel<float>, dim3(nb), dim3(256), 0, s, img, mean, std_, B, C, H, W, Cpad, flip, (float*)out),
+               hipLaunchKernelGGL(prep_input_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, img, mean, std_, B, C, H, W, Cpad, flip, (bf16_t*)out));
+    SDE_CHECK_LAUNCH("sde_prep_input");
+    return SDE_OK;
+}
+
+int sde_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* bnp, sde_stream_t stream) {
+    SDE_CHECK_ARG(part && gamma && beta && bnp && tiles > 0 && C > 0 && count > 0, "sde_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part, tiles, C, (float)count, gamma, beta, running_mean,
+                       running_var, momentum, eps, bnp);
+    SDE_CHECK_LAUNCH("sde_bn_finalize");
+    return SDE_OK;
+}
+
+int sde_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, int C, float* bnp,
+                       sde_stream_t stream) {
+    SDE_CHECK_ARG(gamma && beta && running_mean && running_var && bnp && C > 0, "sde_bn_eval_params: bad argument");
+    hipLaunchKernelGGL(bn_eval_params_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C, bnp);
+    SDE_CHECK_LAUNCH("sde_bn_eval_params");
+    return SDE_OK;
+}
+
+int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu, long M, int C, int dtype, void* out, sde_stream_t stream) {
+    const int V = dtype == SDE_BF16 ? 8 : 4;
+    SDE_CHECK_ARG(y && bnp && out && M > 0 && C > 0 && C % V == 0, "sde_bn_apply: bad argument (C=%d)", C);
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = grid_for(M * (C / V));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)y, bnp, (const float*)residual, relu, M, C, (float*)out),
+               hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, bnp, (const bf16_t*)residual, relu, M, C, (bf16_t*)out));
+    SDE_CHECK_LAUNCH("sde_bn_apply");
+    return SDE_OK;
+}
+
+int sde_reduce_num_blocks(long M) {
+    long nb = (M + 255) / 256;     // >= 256 rows per block
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, const float* gamma, int relu, long M, int C, int dtype, float* part,
+               float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dy, void* dres, sde_stream_t stream) {
+    const int V = dtype == SDE_BF16 ? 8 : 4;
+    SDE_CHECK_ARG(dout && y && bnp && part && coef && dgamma && dbeta && dy && M > 0 && C > 0 && C % V == 0, "sde_bn_bwd: bad argument");
+    SDE_CHECK_ARG(!relu || out, "sde_bn_bwd: relu needs the saved output");
+    (void)gamma;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = sde_reduce_num_blocks(M);
+    const long rpb = (M + nblk - 1) / nblk;
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)y, bnp, relu, M, C, rpb, part),
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part));
+    SDE_CHECK_LAUNCH("sde_bn_bwd/reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, s, part, nblk, C, (float)M, dgamma, dbeta, accumulate_params, coef);
+    SDE_CHECK_LAUNCH("sde_bn_bwd/finalize");
+    const int nb = grid_for(M * (C / V));
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)y, bnp, coef, relu, M, C, (float*)dy, (float*)dres),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, coef, relu, M, C, (bf16_t*)dy, (bf16_t*)dres));
+    SDE_CHECK_LAUNCH("sde_bn_bwd/apply");
+    return SDE_OK;
+}
+
+int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* out, uint8_t* idx, sde_stream_t stream) {
+    const int V = dtype == SDE_BF16 ? 8 : 4;
+    SDE_CHECK_ARG(x && out && idx && B > 0 && H > 1 && W > 1 && C % V == 0, "sde_maxpool_fwd: bad argument");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = grid_for((long)B * OH * OW * (C / V));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, B, H, W, C, OH, OW, (float*)out, idx),
+               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, B, H, W, C, OH, OW, (bf16_t*)out, idx));
+    SDE_CHECK_LAUNCH("sde_maxpool_fwd");
+    return SDE_OK;
+}
+
+int sde_maxpool_bwd(const void* dout, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream) {
+    const int V = dtype == SDE_BF16 ? 8 : 4;
+    SDE_CHECK_ARG(dout && idx && dx && B > 0 && H > 1 && W > 1 && C % V == 0, "sde_maxpool_bwd: bad argument");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = grid_for((long)B * H * W * (C / V));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, idx, B, H, W, C, OH, OW, (float*)dx),
+               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, idx, B, H, W, C, OH, OW, (bf16_t*)dx));
+    SDE_CHECK_LAUNCH("sde_maxpool_bwd");
+    return SDE_OK;
+}
+
+int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias, int accumulate,
+                     sde_stream_t stream) {
+    const int V = dtype == SDE_BF16 ? 8 : 4;
+    SDE_CHECK_ARG(dout && M > 0 && C > 0 && C % V == 0, "sde_act_bwd_bias: bad argument");
+    SDE_CHECK_ARG(act == SDE_ACT_NONE || out, "sde_act_bwd_bias: activation backward needs the saved output");
+    SDE_CHECK_ARG((dbias == nullptr) || (part && Cbias > 0 && Cbias <= C), "sde_act_bwd_bias: bias gradient needs a partial slab");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = sde_reduce_num_blocks(M);
+    const long rpb = (M + nblk - 1) / nblk;
+    float* p = dbias ? part : nullptr;
+    const size_t lds = (size_t)C * sizeof(float);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(act_bwd_bias_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, act, M, C, rpb, (float*)dz, p),
+               hipLaunchKernelGGL(act_bwd_bias_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, act, M, C, rpb, (bf16_t*)dz, p));
+    SDE_CHECK_LAUNCH("sde_act_bwd_bias");
+    if (dbias) {
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sde_cdiv(Cbias, 64)), dim3(64), 0, s, part, nblk, C, Cbias, dbias, accumulate);
+        SDE_CHECK_LAUNCH("sde_act_bwd_bias/finalize");
+    }
+    return SDE_OK;
+}
+
+int sde_refl_fold(const void* dxp, int B, int H, int W, int C, int C0, int upcat, int dtype, void* dx0, void* dx1, sde_stream_t stream) {
+    const int V = dtype == SDE_BF16 ? 8 : 4;
+    SDE_CHECK_ARG(dxp && dx0 && B > 0 && H >= 3 && W >= 3 && C % V == 0, "sde_refl_fold: bad argument");
+    SDE_CHECK_ARG(!upcat || (C0 > 0 && C0 <= C && C0 % V == 0 && H % 2 == 0 && W % 2 == 0 && (C0 == C || dx1)), "sde_refl_fold: bad upcat argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long items = upcat ? (long)B * (H / 2) * (W / 2) * (C0 / V) + (long)B * H * W * ((C - C0) / V) : (long)B * H * W * (C / V);
+    const int nb = grid_for(items);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(refl_fold_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dxp, B, H, W, C, C0, upcat, (float*)dx0, (float*)dx1),
+               hipLaunchKernelGGL(refl_fold_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dxp, B, H, W, C, C0, upcat, (bf16_t*)dx0, (bf16_t*)dx1));
+    SDE_CHECK_LAUNCH("sde_refl_fold");
+    return SDE_OK;
+}
+
+int sde_depth_head_fwd(const void* y, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, float* depth, sde_stream_t stream) {
+    SDE_CHECK_ARG(y && depth && B > 0 && H > 0 && W > 0 && ld > 0 && min_depth > 0 && max_depth > min_depth, "sde_depth_head_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const float mind = 1.0f / max_depth, maxd = 1.0f / min_depth;
+    const int nb = grid_for((long)B * H * W);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(depth_head_fwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)y, B, H, W, ld, mind, maxd, flip, depth),
+               hipLaunchKernelGGL(depth_head_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, B, H, W, ld, mind, maxd, flip, depth));
+    SDE_CHECK_LAUNCH("sde_depth_head_fwd");
+    return SDE_OK;
+}
+
+int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, void* dy,
+                       sde_stream_t stream) {
+    SDE_CHECK_ARG(y && ddepth && dy && B > 0 && H > 0 && W > 0 && ld > 0, "sde_depth_head_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const float mind = 1.0f / max_depth, maxd = 1.0f / min_depth;
+    const int nb = grid_for((long)B * H * W);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(depth_head_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)y, ddepth, B, H, W, ld, mind, maxd, flip, (float*)dy),
+               hipLaunchKernelGGL(depth_head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, ddepth, B, H, W, ld, mind, maxd, flip, (bf16_t*)dy));
+    SDE_CHECK_LAUNCH("sde_depth_head_bwd");
+    return SDE_OK;
+}
+
+int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype, float* part, float* gnp,
+                    void* out, sde_stream_t stream) {
+    SDE_CHECK_ARG(x && gamma && beta && part && gnp && out && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "sde_gn_relu_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)x, HW, C, part),
+               hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)x, HW, C, part));
+    SDE_CHECK_LAUNCH("sde_gn_relu_fwd/stats");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(sde_cdiv(B * G, 64)), dim3(64), 0, s, part, B, C, G, HW, eps, gnp);
+    SDE_CHECK_LAUNCH("sde_gn_relu_fwd/finalize");
+    const int nb = grid_for((long)B * HW * C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, gnp, gamma, beta, B, HW, C, G, relu, (float*)out),
+               hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, gnp, gamma, beta, B, HW, C, G, relu, (bf16_t*)out));
+    SDE_CHECK_LAUNCH("sde_gn_relu_fwd/apply");
+    return SDE_OK;
+}
+
+int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,
+                    float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream) {
+    SDE_CHECK_ARG(dout && out && x && gnp && gamma && part && coef && dgamma && dbeta && dx && C % G == 0, "sde_gn_relu_bwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)x, gnp, HW, C, G, relu, part),
+               hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, HW, C, G, relu, part));
+    SDE_CHECK_LAUNCH("sde_gn_relu_bwd/stats");
+    const int n = B * G > C ? B * G : C;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(sde_cdiv(n, 64)), dim3(64), 0, s, part, gamma, B, C, G, HW, coef, dgamma, dbeta, accumulate_params);
+    SDE_CHECK_LAUNCH("sde_gn_relu_bwd/finalize");
+    const int nb = grid_for((long)B * HW * C);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, gnp, coef, gamma, B, HW, C, G, relu, (float*)dx),
+               hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, coef, gamma, B, HW, C, G, relu, (bf16_t*)dx));
+    SDE_CHECK_LAUNCH("sde_gn_relu_bwd/apply");
+    return SDE_OK;
+}
+
+int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
+                  float beta2, float eps, const float* bias_corr, float grad_scale, int decoupled_wd, sde_stream_t stream) {
+    SDE_CHECK_ARG(p && g && m && v && seg_end && seg_lr && seg_wd && bias_corr && n > 0 && nseg > 0, "sde_adam_step: bad argument");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, bias_corr,
+                       grad_scale, decoupled_wd);
+    SDE_CHECK_LAUNCH("sde_adam_step");
+    return SDE_OK;
+}
+
+}  // extern "C"
