@@ -1,0 +1,373 @@
+"""Autograd wrappers over the convolution engine and its surrounding layers (include/sde_hip.h).
+
+Tensor convention: activations are NHWC torch tensors [B, H, W, C] (float32 or bfloat16), C padded to 16 bytes;
+parameters stay fp32 in the reference's layouts (conv weight OIHW) so state dicts are interchangeable.
+"""
+import ctypes
+from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_long, c_void_p
+
+import torch
+
+from . import lib as L
+
+SRC_PLAIN, SRC_UPCAT, SRC_ZEROINS = 0, 1, 2
+ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
+
+
+class ConvDesc(Structure):
+    _fields_ = [("x0", c_void_p), ("x1", c_void_p), ("dtype", c_int32), ("C0", c_int32), ("C1", c_int32), ("H0", c_int32), ("W0", c_int32),
+                ("IH", c_int32), ("IW", c_int32), ("src_mode", c_int32), ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
+                ("reflect", c_int32), ("Bn", c_int32), ("OH", c_int32), ("OW", c_int32)]
+
+
+_P, _I, _F, _LG = c_void_p, c_int, c_float, c_long
+L.register_protos({
+    "sde_pack_weight": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
+    "sde_conv_fwd": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P], c_int),
+    "sde_conv_fwd_tiles_m": ([POINTER(ConvDesc), _I], c_int),
+    "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
+    "sde_conv_wgrad": ([POINTER(ConvDesc), _P, _I, _I, _I, _P, _I, _P, _I, _P], c_int),
+    "sde_prep_input": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], c_int),
+    "sde_bn_finalize": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P], c_int),
+    "sde_bn_eval_params": ([_P, _P, _P, _P, _F, _I, _P, _P], c_int),
+    "sde_bn_apply": ([_P, _P, _P, _I, _LG, _I, _I, _P, _P], c_int),
+    "sde_reduce_num_blocks": ([_LG], c_int),
+    "sde_bn_bwd": ([_P, _P, _P, _P, _P, _I, _LG, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P], c_int),
+    "sde_maxpool_fwd": ([_P, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
+    "sde_maxpool_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
+    "sde_act_bwd_bias": ([_P, _P, _I, _LG, _I, _I, _P, _P, _P, _I, _I, _P], c_int),
+    "sde_refl_fold": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
+    "sde_depth_head_fwd": ([_P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P], c_int),
+    "sde_depth_head_bwd": ([_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P], c_int),
+    "sde_gn_relu_fwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P], c_int),
+    "sde_gn_relu_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P], c_int),
+    "sde_adam_step": ([_P, _P, _P, _P, _LG, _P, _P, _P, _I, _F, _F, _F, _P, _F, _I, _P], c_int),
+})
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return L.F32
+    if dt == torch.bfloat16:
+        return L.BF16
+    raise L.SdeHipError(f"unsupported activation dtype {dt}")
+
+
+def vec_of(dt):
+    return 4 if dt == torch.float32 else 8
+
+
+def pad_to(c, v):
+    return (c + v - 1) // v * v
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise L.SdeHipError("parameters must be float32")
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# raw (non-autograd) helpers
+# ---------------------------------------------------------------------------------------------------------------
+def pack_weight(w, dtype, cin_pad, cout_pad, for_dgrad=False):
+    w = _f32(w)
+    Cout, Cin, KH, KW = w.shape
+    shape = (cin_pad, KH, KW, cout_pad) if for_dgrad else (cout_pad, KH, KW, cin_pad)
+    out = torch.empty(shape, device=w.device, dtype=dtype)
+    L.check(L.lib().sde_pack_weight(L.ptr(w), L.ptr(out), dtype_code(dtype), Cout, Cin, KH, KW, cin_pad, cout_pad, int(for_dgrad), L.stream()),
+            "sde_pack_weight")
+    return out
+
+
+def _desc(x0, x1, src_mode, KH, KW, stride, pad, reflect, IH, IW, OH, OW):
+    d = ConvDesc()
+    B, H0, W0, C0 = x0.shape
+    d.x0 = x0.data_ptr(); d.x1 = x1.data_ptr() if x1 is not None else 0
+    d.dtype = dtype_code(x0.dtype)
+    d.C0, d.C1, d.H0, d.W0, d.IH, d.IW = C0, (x1.shape[3] if x1 is not None else 0), H0, W0, IH, IW
+    d.src_mode, d.KH, d.KW, d.stride, d.pad, d.reflect = src_mode, KH, KW, stride, pad, int(reflect)
+    d.Bn, d.OH, d.OW = B, OH, OW
+    return d
+
+
+def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device):
+    y = torch.empty(d.Bn, d.OH, d.OW, ldy, device=device, dtype=x_dtype)
+    stats, tiles = None, 0
+    lib = L.lib()
+    if want_stats:
+        tiles = lib.sde_conv_fwd_tiles_m(ctypes.byref(d), ldy)
+        stats = torch.empty(tiles, Cout, 2, device=device, dtype=torch.float32)
+    L.check(lib.sde_conv_fwd(ctypes.byref(d), L.ptr(w_packed), L.ptr(bias), act, L.ptr(y), Cout, ldy, L.ptr(stats), L.stream()), "sde_conv_fwd")
+    return y, stats
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Convolution (+bias, +ELU, optional BatchNorm statistics) with every input mode of the path
+# ---------------------------------------------------------------------------------------------------------------
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, stride, pad, reflect, act, upcat, want_stats):
+        if not x0.is_contiguous() or (x1 is not None and not x1.is_contiguous()):
+            raise L.SdeHipError("conv2d: NHWC inputs must be contiguous")
+        dt = x0.dtype
+        V = vec_of(dt)
+        B, H0, W0, C0 = x0.shape
+        Cout, Cin, KH, KW = weight.shape
+        C1 = x1.shape[3] if x1 is not None else 0
+        if C0 % V or C1 % V:
+            raise L.SdeHipError(f"conv2d: channel counts ({C0},{C1}) must be multiples of {V}")
+        if Cin > C0 + C1 or (upcat and Cin != C0 + C1):
+            raise L.SdeHipError(f"conv2d: weight expects {Cin} input channels, tensors carry {C0}+{C1}")
+        IH, IW = (2 * H0, 2 * W0) if upcat else (H0, W0)
+        OH = (IH + 2 * pad - KH) // stride + 1
+        OW = (IW + 2 * pad - KW) // stride + 1
+        ldy = pad_to(Cout, V)
+        d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
+        wp = pack_weight(weight, dt, C0 + C1, ldy)
+        b32 = _f32(bias) if bias is not None else None
+        y, stats = conv_raw(d, dt, wp, b32, act, Cout, ldy, want_stats, x0.device)
+        ctx.save_for_backward(x0, x1, weight, y if act != ACT_NONE else None)
+        ctx.cfg = (stride, pad, reflect, act, upcat, bias is not None, IH, IW, OH, OW)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dstats=None):
+        x0, x1, weight, y = ctx.saved_tensors
+        stride, pad, reflect, act, upcat, has_bias, IH, IW, OH, OW = ctx.cfg
+        dt = x0.dtype
+        V = vec_of(dt)
+        lib = L.lib()
+        dev = x0.device
+        B, H0, W0, C0 = x0.shape
+        C1 = x1.shape[3] if x1 is not None else 0
+        Cout, Cin, KH, KW = weight.shape
+        ldy = pad_to(Cout, V)
+        dy = dy.contiguous()
+        M = B * OH * OW
+        # 1. activation backward + bias gradient
+        dbias = None
+        dz = dy
+        if act != ACT_NONE or has_bias:
+            nblk = lib.sde_reduce_num_blocks(M)
+            part = torch.empty(nblk, ldy, device=dev) if has_bias else None
+            dbias = torch.empty(Cout, device=dev) if has_bias else None
+            dz = torch.empty_like(dy) if act != ACT_NONE else None
+            L.check(lib.sde_act_bwd_bias(L.ptr(dy), L.ptr(y), act, M, ldy, dtype_code(dt), L.ptr(dz), L.ptr(part), L.ptr(dbias), Cout, 0, L.stream()),
+                    "sde_act_bwd_bias")
+            if dz is None:
+                dz = dy
+        # 2. weight gradient
+        dw = None
+        if ctx.needs_input_grad[2]:
+            d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
+            splits = lib.sde_conv_wgrad_splits(ctypes.byref(d), Cout)
+            slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
+            dw = torch.empty_like(weight)
+            L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw), 0, L.stream()), "sde_conv_wgrad")
+        # 3. data gradient
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            Cv = C0 + C1
+            wd = pack_weight(weight, dt, Cv, ldy, for_dgrad=True)          # [Cv][KH][KW][ldy], taps flipped
+            if reflect:
+                dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1, False, OH, OW, IH + 2, IW + 2)
+                dxp, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev)
+                dx0 = torch.empty_like(x0)
+                dx1 = torch.empty_like(x1) if x1 is not None else None
+                L.check(lib.sde_refl_fold(L.ptr(dxp), B, IH, IW, Cv, C0, int(upcat), dtype_code(dt), L.ptr(dx0), L.ptr(dx1), L.stream()), "sde_refl_fold")
+            else:
+                if upcat:
+                    raise L.SdeHipError("upsample+concat source is only supported with reflection padding (decoder)")
+                if stride == 1:
+                    dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1 - pad, False, OH, OW, IH, IW)
+                elif stride == 2:
+                    # virtual zero-inserted gradient image: Z[2i, 2j] = dz[i, j]
+                    dd = _desc(dz, None, SRC_ZEROINS, KH, KW, 1, KH - 1 - pad, False, 2 * OH - 1, 2 * OW - 1, IH, IW)
+                else:
+                    raise L.SdeHipError(f"stride {stride} not supported")
+                dx0, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev)
+        return dx0, dx1, dw, dbias, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, skip=None, upsample=False, bn_stats=False):
+    """y = act(conv(x) + bias) on NHWC tensors.
+
+    upsample=True: the input is cat(nearest_x2(x), skip) (skip may be None) -- depth_decoder.py:L102-105 -- gathered on the fly.
+    bn_stats=True additionally returns the per-tile (sum, sum^2) slab BatchNorm needs.
+    """
+    return _Conv2d.apply(x, skip, weight, bias, int(stride), int(pad), bool(reflect), int(act), bool(upsample), bool(bn_stats))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BatchNorm (+ReLU, +residual)
+# ---------------------------------------------------------------------------------------------------------------
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, residual, relu, momentum, eps, training):
+        dt = y.dtype
+        C = y.shape[-1]
+        M = y.numel() // C
+        lib = L.lib()
+        dev = y.device
+        bnp = torch.empty(4, C, device=dev)
+        if training:
+            L.check(lib.sde_bn_finalize(L.ptr(stats), stats.shape[0], C, M, L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var),
+                                        momentum, eps, L.ptr(bnp), L.stream()), "sde_bn_finalize")
+        else:
+            L.check(lib.sde_bn_eval_params(L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var), eps, C, L.ptr(bnp), L.stream()),
+                    "sde_bn_eval_params")
+        out = torch.empty_like(y)
+        L.check(lib.sde_bn_apply(L.ptr(y), L.ptr(bnp), L.ptr(residual), int(relu), M, C, dtype_code(dt), L.ptr(out), L.stream()), "sde_bn_apply")
+        ctx.save_for_backward(y, out if relu else None, bnp, gamma)
+        ctx.cfg = (relu, residual is not None, training)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, bnp, gamma = ctx.saved_tensors
+        relu, has_res, training = ctx.cfg
+        if not training:
+            raise L.SdeHipError("BatchNorm backward in eval mode is not on the path")
+        dt = y.dtype
+        C = y.shape[-1]
+        M = y.numel() // C
+        lib = L.lib()
+        dev = y.device
+        dout = dout.contiguous()
+        part = torch.empty(lib.sde_reduce_num_blocks(M), C, 2, device=dev)
+        coef = torch.empty(2, C, device=dev)
+        dgamma = torch.empty(C, device=dev)
+        dbeta = torch.empty(C, device=dev)
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if has_res else None
+        L.check(lib.sde_bn_bwd(L.ptr(dout), L.ptr(out), L.ptr(y), L.ptr(bnp), L.ptr(gamma), int(relu), M, C, dtype_code(dt), L.ptr(part), L.ptr(coef),
+                               L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dy), L.ptr(dres), L.stream()), "sde_bn_bwd")
+        return dy, None, dgamma, dbeta, None, None, dres, None, None, None, None
+
+
+def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=None, relu=True, momentum=0.1, eps=1e-5, training=True):
+    return _BatchNormAct.apply(y, stats, gamma, beta, running_mean, running_var, residual, bool(relu), float(momentum), float(eps), bool(training))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MaxPool 3x3 / 2
+# ---------------------------------------------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty(B, OH, OW, C, device=x.device, dtype=x.dtype)
+        idx = torch.empty(B, OH, OW, C, device=x.device, dtype=torch.uint8)
+        L.check(L.lib().sde_maxpool_fwd(L.ptr(x.contiguous()), B, H, W, C, dtype_code(x.dtype), L.ptr(out), L.ptr(idx), L.stream()), "sde_maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, H, W, C = ctx.shape
+        dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype)
+        L.check(L.lib().sde_maxpool_bwd(L.ptr(dout.contiguous()), L.ptr(idx), B, H, W, C, dtype_code(dout.dtype), L.ptr(dx), L.stream()), "sde_maxpool_bwd")
+        return dx
+
+
+def max_pool_3x3_s2(x):
+    return _MaxPool.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Input preparation and the depth head tail
+# ---------------------------------------------------------------------------------------------------------------
+def prep_input(img, mean, std, dtype, flip=False):
+    """NCHW fp32 image -> (img - mean)/std as NHWC `dtype` with channels padded to 16 bytes (no autograd: images carry no grad)."""
+    if img.dtype != torch.float32:
+        raise L.SdeHipError("prep_input expects a float32 NCHW image")
+    img = img.contiguous()
+    B, C, H, W = img.shape
+    Cp = pad_to(C, vec_of(dtype))
+    out = torch.empty(B, H, W, Cp, device=img.device, dtype=dtype)
+    m = _f32(mean.reshape(-1)) if mean is not None else None
+    s = _f32(std.reshape(-1)) if std is not None else None
+    L.check(L.lib().sde_prep_input(L.ptr(img), L.ptr(m), L.ptr(s), B, C, H, W, Cp, int(bool(flip)), dtype_code(dtype), L.ptr(out), L.stream()), "sde_prep_input")
+    return out
+
+
+class _DepthHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, min_depth, max_depth, flip):
+        B, H, W, ld = y.shape
+        depth = torch.empty(B, 1, H, W, device=y.device, dtype=torch.float32)
+        L.check(L.lib().sde_depth_head_fwd(L.ptr(y.contiguous()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype), L.ptr(depth), L.stream()),
+                "sde_depth_head_fwd")
+        ctx.save_for_backward(y)
+        ctx.cfg = (min_depth, max_depth, flip)
+        return depth
+
+    @staticmethod
+    def backward(ctx, ddepth):
+        (y,) = ctx.saved_tensors
+        min_depth, max_depth, flip = ctx.cfg
+        B, H, W, ld = y.shape
+        dy = torch.empty_like(y)
+        L.check(L.lib().sde_depth_head_bwd(L.ptr(y), L.ptr(ddepth.contiguous().float()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype),
+                                           L.ptr(dy), L.stream()), "sde_depth_head_bwd")
+        return dy, None, None, None
+
+
+def depth_head(y, min_depth, max_depth, flip=False):
+    """softplus + disp_to_depth(...)[1] (+ flip) on channel 0 of y -> [B,1,H,W] fp32 depth."""
+    return _DepthHead.apply(y, float(min_depth), float(max_depth), bool(flip))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GroupNorm + ReLU
+# ---------------------------------------------------------------------------------------------------------------
+class _GroupNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        B, H, W, C = x.shape
+        dev = x.device
+        part = torch.empty(B, 16, C, 2, device=dev)
+        gnp = torch.empty(B, groups, 2, device=dev)
+        out = torch.empty_like(x)
+        L.check(L.lib().sde_gn_relu_fwd(L.ptr(x.contiguous()), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), B, H * W, C, groups, eps, int(relu), dtype_code(x.dtype),
+                                        L.ptr(part), L.ptr(gnp), L.ptr(out), L.stream()), "sde_gn_relu_fwd")
+        ctx.save_for_backward(x, out, gnp, gamma)
+        ctx.cfg = (groups, relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, gnp, gamma = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        B, H, W, C = x.shape
+        dev = x.device
+        part = torch.empty(B, 16, C, 2, device=dev)
+        coef = torch.empty(B, groups, 2, device=dev)
+        dgamma = torch.empty(C, device=dev)
+        dbeta = torch.empty(C, device=dev)
+        dx = torch.empty_like(x)
+        L.check(L.lib().sde_gn_relu_bwd(L.ptr(dout.contiguous()), L.ptr(out), L.ptr(x), L.ptr(gnp), L.ptr(_f32(gamma)), B, H * W, C, groups, int(relu),
+                                        dtype_code(x.dtype), L.ptr(part), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dx), L.stream()), "sde_gn_relu_bwd")
+        return dx, dgamma, dbeta, None, None, None
+
+
+def group_norm_relu(x, gamma, beta, groups=16, eps=1e-5, relu=True):
+    if x.shape[-1] != gamma.numel():
+        raise L.SdeHipError("group_norm_relu: channel padding is not supported (PoseNet channels are multiples of 16)")
+    return _GroupNormReLU.apply(x, gamma, beta, int(groups), float(eps), bool(relu))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Fused Adam / AdamW over a flat buffer
+# ---------------------------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, decoupled_wd=False):
+    n = p.numel()
+    L.check(L.lib().sde_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, L.ptr(seg_end), L.ptr(seg_lr), L.ptr(seg_wd), seg_end.numel(), beta1, beta2, eps,
+                                  L.ptr(bias_corr), grad_scale, int(decoupled_wd), L.stream()), "sde_adam_step")

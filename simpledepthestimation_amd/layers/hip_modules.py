@@ -1,0 +1,76 @@
+"""Parameter-holding building blocks whose forward runs on libsde_hip.so (NHWC activations).
+
+Parameter names/layouts equal torch's (``weight`` OIHW fp32, ``bias``, BatchNorm ``running_mean`` ...), so the reference's
+checkpoints load with ``load_state_dict`` unchanged.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..hip import nn as HN
+
+
+class HipConv2d(nn.Module):
+    """nn.Conv2d stand-in (weights only); the arithmetic is sde_conv_fwd / sde_conv_wgrad (include/sde_hip.h)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, reflect=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = int(in_channels), int(out_channels), int(kernel_size)
+        self.stride, self.padding, self.reflect = int(stride), int(padding), bool(reflect)
+        self.weight = nn.Parameter(torch.empty(self.out_channels, self.in_channels, self.kernel_size, self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(self.out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):   # torch.nn.Conv2d default initialisation
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(self.in_channels * self.kernel_size ** 2)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, skip=None, upsample=False, act=HN.ACT_NONE, bn_stats=False):
+        return HN.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.reflect, act, skip, upsample, bn_stats)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, reflect={self.reflect}"
+
+
+class HipBatchNorm2d(nn.Module):
+    """nn.BatchNorm2d stand-in: batch statistics come from the producing convolution's epilogue (stats slab)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = int(num_features), eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, y, stats, residual=None, relu=True):
+        if self.training:
+            self.num_batches_tracked.add_(1)
+        return HN.batch_norm_act(y, stats, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.momentum, self.eps,
+                                 self.training)
+
+
+class HipGroupNorm(nn.Module):
+    """nn.GroupNorm stand-in fused with the following ReLU (PoseNet.py:L13-20)."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+
+    def forward(self, x, relu=True):
+        return HN.group_norm_relu(x, self.weight, self.bias, self.num_groups, self.eps, relu)
+
+
+def conv_bn(conv, bn, x, residual=None, relu=True):
+    """conv -> training-mode BatchNorm [-> + residual] [-> ReLU]; in eval mode BN uses its running statistics."""
+    if bn.training:
+        y, stats = conv(x, bn_stats=True)
+    else:
+        y, stats = conv(x), None
+    return bn(y, stats, residual, relu)

@@ -1,0 +1,107 @@
+"""ResNet-18/34/50 encoder on the HIP convolution engine.
+
+Reference: detectron2/layers/resnet_encoder.py:L61-99 (ResnetEncoder: 5 features = relu(bn1(conv1)), layer1(maxpool), layer2-4)
+wrapping torchvision 0.9 resnetXX (v1.5: stride on the 3x3 of a Bottleneck; kaiming-normal fan_out convs, BN gamma=1/beta=0).
+Attribute / state-dict names follow torchvision (``encoder.conv1``, ``encoder.layer1.0.bn2``, ``...downsample.0``, ``encoder.fc``).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..hip import nn as HN
+from .hip_modules import HipBatchNorm2d, HipConv2d, conv_bn
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = HipConv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = HipBatchNorm2d(planes)
+        self.conv2 = HipConv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = HipBatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x, relu=False)
+        out = conv_bn(self.conv1, self.bn1, x)
+        return conv_bn(self.conv2, self.bn2, out, residual=idt, relu=True)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = HipConv2d(inplanes, planes, 1, 1, 0, bias=False)
+        self.bn1 = HipBatchNorm2d(planes)
+        self.conv2 = HipConv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = HipBatchNorm2d(planes)
+        self.conv3 = HipConv2d(planes, planes * 4, 1, 1, 0, bias=False)
+        self.bn3 = HipBatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x, relu=False)
+        out = conv_bn(self.conv1, self.bn1, x)
+        out = conv_bn(self.conv2, self.bn2, out)
+        return conv_bn(self.conv3, self.bn3, out, residual=idt, relu=True)
+
+
+class ResNet(nn.Module):
+    """torchvision-shaped container (conv1, bn1, layer1..4, fc); ``fc`` is kept only so checkpoints load."""
+
+    def __init__(self, block, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = HipConv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = HipBatchNorm2d(64)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, HipConv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(HipConv2d(self.inplanes, planes * block.expansion, 1, stride, 0, bias=False),
+                                       HipBatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+_SPECS = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]), 50: (Bottleneck, [3, 4, 6, 3])}
+
+
+class ResnetEncoder(nn.Module):
+    def __init__(self, num_layers, pretrained=False, num_input_images=1, norm_layer=None):
+        super().__init__()
+        if num_layers not in _SPECS:
+            raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
+        if pretrained:
+            raise RuntimeError("ImageNet weights cannot be downloaded here; load them from a local checkpoint with load_state_dict "
+                               "(use ENCODER_NAME '18'/'50' instead of '18pt'/'50pt')")
+        if num_input_images != 1 or norm_layer is not None:
+            raise NotImplementedError("multi-image / custom-norm encoders are not on the path")
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        block, layers = _SPECS[num_layers]
+        self.encoder = ResNet(block, layers)
+        if num_layers > 34:
+            self.num_ch_enc[1:] *= 4
+
+    def forward(self, x):
+        """x: NHWC normalised image (channels padded).  Returns the 5 NHWC feature maps."""
+        e = self.encoder
+        self.features = [conv_bn(e.conv1, e.bn1, x)]
+        self.features.append(e.layer1(HN.max_pool_3x3_s2(self.features[-1])))
+        self.features.append(e.layer2(self.features[-1]))
+        self.features.append(e.layer3(self.features[-1]))
+        self.features.append(e.layer4(self.features[-1]))
+        return self.features

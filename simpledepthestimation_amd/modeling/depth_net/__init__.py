@@ -1,0 +1,2 @@
+from .build import DEPTH_NET_REGISTRY, build_depth_net  # noqa: F401
+from .DepthResNet import DepthResNet  # noqa: F401

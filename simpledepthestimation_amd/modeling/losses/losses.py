@@ -1,0 +1,19 @@
+"""SILog / variance losses (reference: detectron2/modeling/losses/losses.py:L5-18) on the HIP path."""
+import torch.nn as nn
+
+from ...hip import photometric as HP
+
+
+class silog_loss(nn.Module):
+    """forward(depth_est, depth_gt): masked (gt > 1) scale-invariant log loss x10.
+
+    depth_gt may be at a HIGHER resolution than depth_est: it is then nearest-sampled inside the kernel, which is what
+    Supervised.py:L44-45 does with resize_img(..., mode='nearest') before calling the loss.
+    """
+
+    def __init__(self, variance_focus):
+        super().__init__()
+        self.variance_focus = variance_focus
+
+    def forward(self, depth_est, depth_gt):
+        return HP.silog_loss(depth_est, depth_gt, self.variance_focus)

@@ -1,0 +1,303 @@
+"""GPU parity: convolution engine + surrounding layers (through the C ABI) vs plain torch-CPU fp32 ops.
+
+fp32 mode is held to ~1e-5 (f32 MFMA is an exact fmaf chain; only summation order differs); bf16 mode is checked against
+an fp32 reference evaluated on the bf16-rounded operands with a tolerance that reflects bf16 output rounding (2^-8 rel).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+@pytest.fixture(scope="module")
+def NN():
+    from simpledepthestimation_amd.hip import nn
+    return nn
+
+
+def nhwc(x, dtype, V):
+    """NCHW fp32 cpu -> NHWC device tensor with channel padding."""
+    B, C, H, W = x.shape
+    Cp = (C + V - 1) // V * V
+    out = torch.zeros(B, H, W, Cp, dtype=dtype)
+    out[..., :C] = x.permute(0, 2, 3, 1).to(dtype)
+    return out.to(dev).contiguous()
+
+
+def nchw(y, C):
+    return y[..., :C].float().permute(0, 3, 1, 2).cpu()
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def check(a, b, dtype, name, f32_tol=2e-5, bf16_tol=1.5e-2):
+    e = relerr(a, b)
+    tol = f32_tol if dtype == torch.float32 else bf16_tol
+    assert e < tol, f"{name}: relative L2 error {e:.3e} > {tol}"
+    mx = (a.double() - b.double()).abs().max().item()
+    scale = b.abs().max().item() + 1e-30
+    assert mx / scale < tol * 50, f"{name}: max abs error {mx:.3e} (scale {scale:.3e})"
+
+
+CONV_CASES = [
+    # name, B, H, W, Cin, Cout, k, stride, pad, reflect, bias, act
+    ("3x3_s1_64_64", 2, 24, 40, 64, 64, 3, 1, 1, False, False, 0),
+    ("3x3_s2_64_128", 2, 24, 40, 64, 128, 3, 2, 1, False, False, 0),
+    ("1x1_s1_256_64", 2, 12, 20, 256, 64, 1, 1, 0, False, False, 0),
+    ("1x1_s2_64_256", 2, 24, 40, 64, 256, 1, 2, 0, False, False, 0),
+    ("7x7_s2_stem", 2, 32, 64, 3, 64, 7, 2, 3, False, False, 0),
+    ("refl_32_16_elu", 2, 16, 24, 32, 16, 3, 1, 1, True, True, 1),
+    ("refl_16_1_head", 2, 16, 24, 16, 1, 3, 1, 1, True, True, 0),
+    ("3x3_256_512_tinyM", 2, 6, 10, 256, 512, 3, 1, 1, False, False, 0),
+    ("k5_s2_pose", 2, 24, 40, 16, 32, 5, 2, 2, False, True, 0),
+    ("k7_s2_pose_in9", 2, 32, 64, 9, 16, 7, 2, 3, False, True, 0),
+    ("3x3_bigM_64_128", 2, 96, 160, 64, 128, 3, 1, 1, False, False, 0),
+    ("3x3_s2_odd", 1, 13, 21, 32, 32, 3, 2, 1, False, True, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_bwd(NN, case, dtype):
+    name, B, H, W, Cin, Cout, k, stride, pad, reflect, has_bias, act = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    V = 4 if dtype == torch.float32 else 8
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
+    if dtype == torch.bfloat16:   # reference sees the same rounded operands
+        x = x.bfloat16().float(); w = w.bfloat16().float()
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    xin = F.pad(xr, (1, 1, 1, 1), mode="reflect") if reflect else xr
+    yr = F.conv2d(xin, wr, br, stride, 0 if reflect else pad)
+    if act == 1:
+        yr = F.elu(yr)
+    gy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    yr.backward(gy)
+
+    xd = nhwc(x, dtype, V).requires_grad_(True)
+    wd = w.clone().to(dev).requires_grad_(True)
+    bd = b.clone().to(dev).requires_grad_(True) if has_bias else None
+    y = NN.conv2d(xd, wd, bd, stride=stride, pad=pad, reflect=reflect, act=act)
+    assert y.shape[:3] == (B, yr.shape[2], yr.shape[3])
+    if y.shape[3] > Cout:
+        assert (y[..., Cout:] == 0).all(), "padded output channels must be exact zeros"
+    check(nchw(y, Cout), yr.detach(), dtype, "y")
+    y.backward(nhwc(gy, dtype, V))
+    check(wd.grad.cpu(), wr.grad, dtype, "dW")
+    check(nchw(xd.grad, Cin), xr.grad, dtype, "dX")
+    if has_bias:
+        check(bd.grad.cpu(), br.grad, dtype, "dbias")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("C0,C1,Cout", [(32, 64, 32), (16, 0, 16), (256, 1024, 256), (64, 64, 128)])
+def test_conv_upsample_concat(NN, dtype, C0, C1, Cout):
+    """depth_decoder.py:L102-105: upconv(i,1)(cat(upsample(x), skip)) with reflection pad, bias, ELU -- gathered on the fly."""
+    g = torch.Generator().manual_seed(C0 + C1)
+    V = 4 if dtype == torch.float32 else 8
+    B, h, w = 2, 6, 10
+    x0 = torch.randn(B, C0, h, w, generator=g)
+    x1 = torch.randn(B, C1, 2 * h, 2 * w, generator=g) if C1 else None
+    wt = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt((C0 + C1) * 9)
+    bs = torch.randn(Cout, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        x0 = x0.bfloat16().float(); wt = wt.bfloat16().float()
+        x1 = x1.bfloat16().float() if C1 else None
+    x0r = x0.clone().requires_grad_(True); x1r = x1.clone().requires_grad_(True) if C1 else None
+    wr = wt.clone().requires_grad_(True); br = bs.clone().requires_grad_(True)
+    up = F.interpolate(x0r, scale_factor=2, mode="nearest")
+    cat = torch.cat([up, x1r], 1) if C1 else up
+    yr = F.elu(F.conv2d(F.pad(cat, (1, 1, 1, 1), mode="reflect"), wr, br))
+    gy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    yr.backward(gy)
+    x0d = nhwc(x0, dtype, V).requires_grad_(True)
+    x1d = nhwc(x1, dtype, V).requires_grad_(True) if C1 else None
+    wd = wt.clone().to(dev).requires_grad_(True); bd = bs.clone().to(dev).requires_grad_(True)
+    y = NN.conv2d(x0d, wd, bd, stride=1, pad=1, reflect=True, act=1, skip=x1d, upsample=True)
+    check(nchw(y, Cout), yr.detach(), dtype, "y")
+    y.backward(nhwc(gy, dtype, V))
+    check(wd.grad.cpu(), wr.grad, dtype, "dW")
+    check(bd.grad.cpu(), br.grad, dtype, "dbias")
+    check(nchw(x0d.grad, C0), x0r.grad, dtype, "dx0 (through nearest-upsample)")
+    if C1:
+        check(nchw(x1d.grad, C1), x1r.grad, dtype, "dx1 (skip)")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("C,with_res,relu", [(64, False, True), (128, True, True), (256, False, False)])
+def test_conv_batchnorm(NN, dtype, C, with_res, relu):
+    """conv (stats in the GEMM epilogue) -> training-mode BatchNorm [+ residual] [+ ReLU], forward and backward."""
+    g = torch.Generator().manual_seed(C)
+    V = 4 if dtype == torch.float32 else 8
+    B, H, W, Cin = 3, 14, 22, 32
+    x = torch.randn(B, Cin, H, W, generator=g) + 0.3
+    w = torch.randn(C, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.2
+    res = torch.randn(B, C, H, W, generator=g) if with_res else None
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float(); w = w.bfloat16().float()
+        res = res.bfloat16().float() if with_res else None
+    xr, wr, gr, br = (t.clone().requires_grad_(True) for t in (x, w, gamma, beta))
+    rr = res.clone().requires_grad_(True) if with_res else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    yc = F.conv2d(xr, wr, None, 1, 1)
+    if dtype == torch.bfloat16:   # the GPU path stores the conv output in bf16 before normalising
+        yc = yc + (yc.detach().bfloat16().float() - yc.detach())
+    o = F.batch_norm(yc, rm, rv, gr, br, True, 0.1, 1e-5)
+    if with_res:
+        o = o + rr
+    if relu:
+        o = F.relu(o)
+    go = torch.randn(o.shape, generator=g)
+    if dtype == torch.bfloat16:
+        go = go.bfloat16().float()
+    o.backward(go)
+    xd = nhwc(x, dtype, V).requires_grad_(True)
+    wd, gd, bd = (t.clone().to(dev).requires_grad_(True) for t in (w, gamma, beta))
+    rd = nhwc(res, dtype, V).requires_grad_(True) if with_res else None
+    rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y, stats = NN.conv2d(xd, wd, None, stride=1, pad=1, bn_stats=True)
+    out = NN.batch_norm_act(y, stats, gd, bd, rmd, rvd, residual=rd, relu=relu)
+    check(nchw(out, C), o.detach(), dtype, "bn out")
+    check(rmd.cpu(), rm, dtype, "running_mean", 1e-5, 1e-2)
+    check(rvd.cpu(), rv, dtype, "running_var", 1e-5, 1e-2)
+    out.backward(nhwc(go, dtype, V))
+    check(gd.grad.cpu(), gr.grad, dtype, "dgamma", 5e-5, 3e-2)
+    check(bd.grad.cpu(), br.grad, dtype, "dbeta", 5e-5, 3e-2)
+    check(nchw(xd.grad, Cin), xr.grad, dtype, "dX", 5e-5, 3e-2)
+    check(wd.grad.cpu(), wr.grad, dtype, "dW", 5e-5, 3e-2)
+    if with_res:
+        check(nchw(rd.grad, C), rr.grad, dtype, "dres")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_maxpool(NN, dtype):
+    g = torch.Generator().manual_seed(1)
+    V = 4 if dtype == torch.float32 else 8
+    for (B, C, H, W) in [(2, 64, 16, 24), (1, 16, 13, 21)]:
+        x = torch.randn(B, C, H, W, generator=g)
+        if dtype == torch.bfloat16:
+            x = x.bfloat16().float()
+        xr = x.clone().requires_grad_(True)
+        yr = F.max_pool2d(xr, 3, 2, 1)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        xd = nhwc(x, dtype, V).requires_grad_(True)
+        y = NN.max_pool_3x3_s2(xd)
+        assert torch.equal(nchw(y, C), yr.detach())
+        y.backward(nhwc(gy, dtype, V))
+        check(nchw(xd.grad, C), xr.grad.to(dtype).float(), dtype, "maxpool dx", 1e-6, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("flip", [False, True])
+def test_depth_head(NN, dtype, flip):
+    g = torch.Generator().manual_seed(2)
+    V = 4 if dtype == torch.float32 else 8
+    B, H, W = 2, 12, 20
+    y = torch.randn(B, 1, H, W, generator=g) * 3
+    y[0, 0, 0, 0] = 25.0   # softplus threshold branch
+    if dtype == torch.bfloat16:
+        y = y.bfloat16().float()
+    yr = y.clone().requires_grad_(True)
+    sd = 1 / 80 + (1 / 0.1 - 1 / 80) * F.softplus(yr)
+    dr = 1 / sd
+    if flip:
+        dr = torch.flip(dr, [3])
+    gd = torch.randn(dr.shape, generator=g)
+    dr.backward(gd)
+    yd = nhwc(y, dtype, V).requires_grad_(True)
+    d = NN.depth_head(yd, 0.1, 80.0, flip)
+    assert d.dtype == torch.float32 and d.shape == (B, 1, H, W)
+    check(d.cpu(), dr.detach(), torch.float32, "depth", 1e-5)
+    d.backward(gd.to(dev))
+    assert (yd.grad[..., 1:] == 0).all()
+    check(nchw(yd.grad, 1), yr.grad, dtype, "d logit", 2e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("C,H,W", [(16, 24, 40), (32, 12, 20), (256, 3, 5), (256, 2, 5)])
+def test_group_norm_relu(NN, dtype, C, H, W):
+    g = torch.Generator().manual_seed(C + H)
+    V = 4 if dtype == torch.float32 else 8
+    B = 3
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    o = F.relu(F.group_norm(xr, 16, gr, br, 1e-5))
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    xd = nhwc(x, dtype, V).requires_grad_(True)
+    gd, bd = (t.clone().to(dev).requires_grad_(True) for t in (gamma, beta))
+    out = NN.group_norm_relu(xd, gd, bd, 16, 1e-5)
+    check(nchw(out, C), o.detach(), dtype, "gn out")
+    out.backward(nhwc(go, dtype, V))
+    check(nchw(xd.grad, C), xr.grad, dtype, "gn dx", 5e-5, 3e-2)
+    check(gd.grad.cpu(), gr.grad, dtype, "gn dgamma", 5e-5, 3e-2)
+    check(bd.grad.cpu(), br.grad, dtype, "gn dbeta", 5e-5, 3e-2)
+
+
+def test_prep_input(NN):
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(2, 3, 10, 14, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406]); std = torch.tensor([0.229, 0.224, 0.225])
+    ref = (img - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    for dtype, V in [(torch.float32, 4), (torch.bfloat16, 8)]:
+        for flip in (False, True):
+            out = NN.prep_input(img.to(dev), mean.to(dev), std.to(dev), dtype, flip)
+            assert out.shape == (2, 10, 14, V) and (out[..., 3:] == 0).all()
+            r = torch.flip(ref, [3]) if flip else ref
+            check(nchw(out, 3), r, dtype, "prep_input", 1e-6, 5e-3)
+    nine = torch.rand(2, 9, 6, 8, generator=g)
+    out = NN.prep_input(nine.to(dev), None, None, torch.float32)
+    assert out.shape == (2, 6, 8, 12)
+    assert torch.equal(nchw(out, 9), nine)
+
+
+@pytest.mark.parametrize("decoupled", [False, True])
+def test_adam_step(NN, decoupled):
+    g = torch.Generator().manual_seed(4)
+    n1, n2 = 1000, 777
+    p = torch.randn(n1 + n2, generator=g); gr = torch.randn(n1 + n2, generator=g)
+    pa, pb = p[:n1].clone().requires_grad_(True), p[n1:].clone().requires_grad_(True)
+    groups = [{"params": [pa], "lr": 2e-4, "weight_decay": 1e-2 if decoupled else 0.0}, {"params": [pb], "lr": 1e-4, "weight_decay": 0.0}]
+    opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)(groups, eps=1e-6)
+    pd, m, v = p.clone().to(dev), torch.zeros(n1 + n2, device=dev), torch.zeros(n1 + n2, device=dev)
+    seg_end = torch.tensor([n1, n1 + n2], dtype=torch.long, device=dev)
+    seg_lr = torch.tensor([2e-4, 1e-4], device=dev); seg_wd = torch.tensor([1e-2 if decoupled else 0.0, 0.0], device=dev)
+    for t in range(1, 4):
+        gt = gr * (1.0 + 0.1 * t)
+        pa.grad, pb.grad = gt[:n1].clone(), gt[n1:].clone()
+        opt.step()
+        bc = torch.tensor([1 - 0.9 ** t, 1 - 0.999 ** t], device=dev)
+        NN.adam_step(pd, gt.to(dev), m, v, seg_end, seg_lr, seg_wd, bc, eps=1e-6, decoupled_wd=decoupled)
+    ref = torch.cat([pa.detach(), pb.detach()])
+    assert (pd.cpu() - ref).abs().max().item() < 1e-6
+
+
+def test_full_size_conv_properties(NN):
+    """BASELINE size (B=12, 48x160, 64->64 3x3, bf16): linearity in the input and agreement of a strided sub-sample with fp32 CPU."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C = 12, 48, 160, 64
+    x1 = torch.randn(B, H, W, C, generator=g).bfloat16().to(dev); x2 = torch.randn(B, H, W, C, generator=g).bfloat16().to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) / 24).bfloat16().float().to(dev)
+    y1 = NN.conv2d(x1, w, None, stride=1, pad=1).float(); y2 = NN.conv2d(x2, w, None, stride=1, pad=1).float()
+    y12 = NN.conv2d((x1.float() + x2.float()).bfloat16(), w, None, stride=1, pad=1).float()
+    assert relerr(y12.cpu(), (y1 + y2).cpu()) < 2e-2
+    ref = F.conv2d(x1[:2].float().permute(0, 3, 1, 2).cpu(), w.cpu(), None, 1, 1)
+    check(nchw(y1[:2].to(torch.bfloat16), C), ref, torch.bfloat16, "sub-sample vs fp32 cpu")
