@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json: training images/sec at 192x640, bs=12/GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (N=1 and per rank for N>1): BASELINE.json configs[1] -- Supervised ResNet-50, bf16 storage / fp32 accumulate,
+bs=12, 192x640, synthetic KITTI-shaped batches, random-init weights.  One "step" = zero-grad + forward +
+backward (+ RCCL all-reduce of the flat gradient for N>1) + fused AdamW, exactly what projects/Supervised/train.py:L99-128 does.
+Inputs are resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line (tier contract):
+  roofline     -- dominant kernel family by device time (the implicit-GEMM convolution kernel), algorithmic FLOPs / measured
+                  duration, from an event-instrumented pass of the same step inside this process (events on the launch stream).
+  cpu_baseline -- the CPU oracle (torch-CPU restatement of the reference, "port") timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}    # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+WORKLOADS = {
+    "sup_r50": dict(arch="SupDepthModel", enc="50", desc="Supervised ResNet-50 (BASELINE configs[1])"),
+    "sup_r18": dict(arch="SupDepthModel", enc="18", desc="Supervised ResNet-18"),
+    "mono_r18": dict(arch="MonoDepth2Model", enc="18", desc="MonoDepth2 ResNet-18 3-frame (BASELINE configs[2])"),
+    "mono_r50": dict(arch="MonoDepth2Model", enc="50", desc="MonoDepth2 ResNet-50 3-frame (BASELINE configs[3])"),
+}
+
+
+def synth_batch(arch, B, H, W, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    if arch == "SupDepthModel":
+        img = torch.rand(B, 3, H, W, generator=g)
+        m = torch.rand(B, 1, H, W, generator=g) < 0.3
+        depth = torch.where(m, torch.rand(B, 1, H, W, generator=g) * 79 + 1, torch.zeros(1))
+        batch = {"img": img, "depth": depth}
+    else:
+        from oracle.gen_golden import kitti_K, smooth_images       # input synthesis only (shared with the tests)
+        a, b, c = smooth_images(g, B, H, W)
+        batch = {"img": a, "img_orig": a.clone(), "ctx_img": [b, c], "ctx_img_orig": [b.clone(), c.clone()], "intrinsics": kitti_K(B, H, W)}
+    return {k: ([x.to(device) for x in v] if isinstance(v, list) else v.to(device)) for k, v in batch.items()}
+
+
+def build(args, device):
+    from simpledepthestimation_amd.config import get_cfg
+    from simpledepthestimation_amd.engine import trainer as T
+    from simpledepthestimation_amd.modeling import build_model
+    wl = WORKLOADS[args.workload]
+    cfg = get_cfg()
+    cfg.MODEL.META_ARCHITECTURE = wl["arch"]
+    cfg.MODEL.DEPTH_NET.ENCODER_NAME = wl["enc"]
+    cfg.MODEL.COMPUTE_DTYPE = args.dtype
+    cfg.MODEL.DEVICE = str(device)
+    cfg.SOLVER.DEPTH_LR = 1e-4 if wl["arch"] == "SupDepthModel" else 2e-4
+    torch.manual_seed(0)
+    model = build_model(cfg).train()
+    mk = T.supervised_trainer if wl["arch"] == "SupDepthModel" else T.monodepth2_trainer
+    trainer = mk(model, cfg, use_graph=not args.no_graph)
+    return cfg, model, trainer
+
+
+def roofline_pass(trainer, batch, steps, dtype):
+    """Event-instrumented eager steps of the same workload: per GEMM launch (kind, tile variant) duration and algorithmic FLOPs."""
+    from simpledepthestimation_amd.hip import lib as L
+    trainer._fwd_bwd(batch)                      # eager warm-up (the timed region may have run under graph replay)
+    torch.cuda.synchronize()
+    L.PROFILE = []
+    for _ in range(steps):
+        trainer._fwd_bwd(batch)
+    torch.cuda.synchronize()
+    recs, L.PROFILE = L.PROFILE, None
+    fam = {}
+    for kind, flops, variant, e0, e1 in recs:
+        key = ("igemm" if kind.startswith("igemm") else kind, variant)
+        f = fam.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        f["ms"] += e0.elapsed_time(e1); f["flops"] += flops; f["launches"] += 1
+    dom_key = max(fam, key=lambda k: fam[k]["ms"])
+    dom = fam[dom_key]
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    tot_ms = sum(f["ms"] for f in fam.values()); tot_fl = sum(f["flops"] for f in fam.values())
+    name = f"igemm_kernel<{dtype},{dom_key[1] // 1000}x{dom_key[1] % 1000}>" if dom_key[0] == "igemm" else "wgrad_kernel+wgrad_reduce_kernel"
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": name, "launches_per_step": dom["launches"] // steps, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+            "gemm_flops_per_step": tot_fl / steps, "gemm_ms_per_step": round(tot_ms / steps, 3),
+            "all_gemm_achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+            "families": {f"{k[0]}:{k[1]}": {"ms_per_step": round(v["ms"] / steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                            "launches_per_step": v["launches"] // steps} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
+def cpu_baseline(args):
+    """The CPU oracle (kind "port": our torch-CPU restatement, pinned to the reference by tests/golden) on a bounded sample."""
+    from oracle import models as OM
+    wl = WORKLOADS[args.workload]
+    enc = int(wl["enc"])
+    B, H, W = args.cpu_batch, args.height, args.width
+    threads = torch.get_num_threads()
+    sd = OM.init_state_dict(enc, with_pose=wl["arch"] != "SupDepthModel", seed=0)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k and "pixel" not in k and ".fc." not in k}
+    state = dict(sd); state.update(leaves)
+    opt = torch.optim.AdamW(list(leaves.values()), lr=1e-4, eps=1e-6) if wl["arch"] == "SupDepthModel" else torch.optim.Adam(list(leaves.values()), lr=2e-4)
+    batch = synth_batch(wl["arch"], B, H, W, 1, "cpu")
+
+    def step():
+        opt.zero_grad()
+        if wl["arch"] == "SupDepthModel":
+            out = OM.supervised_forward(state, batch, enc, update_running=True)
+            loss = out["silog_loss"]
+        else:
+            out = OM.monodepth2_forward(state, batch, enc, update_running=True)
+            loss = out["rec_loss"] + out["smooth_loss"]
+        loss.backward()
+        opt.step()
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < args.cpu_steps:
+        step(); n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} timed fp32 training steps (fwd+bwd+optimizer) of the CPU oracle at bs={B}, {H}x{W}, after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="sup_r50", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline object (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    cfg, model, trainer = build(args, device)
+    batch = synth_batch(WORKLOADS[args.workload]["arch"], args.batch, args.height, args.width, 1000 + rank, device)
+
+    for _ in range(args.warmup):
+        losses = trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final = {k: float(v.item()) for k, v in losses.items()}
+    assert all(x == x and abs(x) != float("inf") for x in final.values()), f"non-finite loss {final}"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        out = {"metric": "training images/sec at 192x640 bs=12/GPU", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+               "config": {"workload": f"{WORKLOADS[args.workload]['desc']}, {args.dtype} storage / fp32 accumulate, bs={args.batch}/GPU, "
+                                      f"{args.height}x{args.width}, fwd+bwd+optimizer, random-init weights", "global_batch": args.batch * world,
+                          "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+               "final_losses": final}
+        if args.profile_steps > 0:
+            out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,7 @@ int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int
 int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
                  sde_stream_t stream);
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy);
+int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy); /* tile the dispatcher picks: BM*1000 + BN (profiling aid) */
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).
  * slab: caller workspace [splits][Cout][KH*KW*(C0+C1)] fp32, splits = sde_conv_wgrad_splits(d, Cout). */

@@ -506,7 +506,7 @@ int launch_igemm(const IGemmP& p, hipStream_t s) {
     constexpr int lds = stage > ctile ? stage : ctile;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     dim3 grid(sde_cdiv(p.g.M, BM), sde_cdiv(p.ldy, BN));
@@ -514,20 +514,25 @@ int launch_igemm(const IGemmP& p, hipStream_t s) {
     return 0;
 }
 
+// Tile choice (one place): returns BM*1000 + BN.  Small-N layers get narrow N tiles (the GEMM is then A-bandwidth bound);
+// layers whose 128x128 grid would not fill the 256 CUs fall back to 64x64 tiles.
+int pick_tile(long M, int N) {
+    const long tiles128 = (long)sde_cdiv(M, 128) * sde_cdiv(N, 128);
+    if (N > 64) return (tiles128 < 192) ? 64064 : 128128;
+    if (N > 32) return (sde_cdiv(M, 128) < 192) ? 64064 : 128064;
+    if (N > 16) return 128032;
+    return 128016;
+}
+
 template <typename T>
 int dispatch_igemm(const IGemmP& p, hipStream_t s) {
-    const int N = p.ldy;
-    const long tiles128 = (long)sde_cdiv(p.g.M, 128) * sde_cdiv(N, 128);
-    if (N > 64) {
-        if (tiles128 < 192 && N >= 64) return launch_igemm<T, 64, 64, 2, 2>(p, s);
-        return launch_igemm<T, 128, 128, 2, 2>(p, s);
+    switch (pick_tile(p.g.M, p.ldy)) {
+        case 128128: return launch_igemm<T, 128, 128, 2, 2>(p, s);
+        case 128064: return launch_igemm<T, 128, 64, 2, 2>(p, s);
+        case 128032: return launch_igemm<T, 128, 32, 4, 1>(p, s);
+        case 128016: return launch_igemm<T, 128, 16, 4, 1>(p, s);
+        default: return launch_igemm<T, 64, 64, 2, 2>(p, s);
     }
-    if (N > 32) {
-        if ((long)sde_cdiv(p.g.M, 128) < 192) return launch_igemm<T, 64, 64, 2, 2>(p, s);
-        return launch_igemm<T, 128, 64, 2, 2>(p, s);
-    }
-    if (N > 16) return launch_igemm<T, 128, 32, 4, 1>(p, s);
-    return launch_igemm<T, 128, 16, 4, 1>(p, s);
 }
 
 template <typename T, int BMG, int BNG, int WM, int WN>
@@ -536,7 +541,7 @@ int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
     constexpr int lds = 2 * BR * (BMG * (int)sizeof(T) + 16) + 2 * BR * (BNG * (int)sizeof(T) + 16);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMG, BNG, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMG, BNG, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     dim3 grid(sde_cdiv(p.Cout, BMG), sde_cdiv(p.g.Ktot, BNG), splits);
@@ -600,15 +605,12 @@ int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias
     return SDE_OK;
 }
 
+int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) { return pick_tile((long)d->Bn * d->OH * d->OW, ldy); }
+
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
     // number of M tiles the dispatcher will use (= rows of the BN-statistics slab)
     const long M = (long)d->Bn * d->OH * d->OW;
-    const int N = ldy;
-    const long tiles128 = (long)sde_cdiv(M, 128) * sde_cdiv(N, 128);
-    int bm = 128;
-    if (N > 64) bm = (tiles128 < 192) ? 64 : 128;
-    else if (N > 32) bm = (sde_cdiv(M, 128) < 192) ? 64 : 128;
-    return sde_cdiv(M, bm);
+    return sde_cdiv(M, pick_tile(M, ldy) / 1000);
 }
 
 int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {

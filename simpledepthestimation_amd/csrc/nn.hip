@@ -768,7 +768,7 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
 
 int sde_refl_fold(const void* dxp, int B, int H, int W, int C, int C0, int upcat, int dtype, void* dx0, void* dx1, sde_stream_t stream) {
     const int V = dtype == SDE_BF16 ? 8 : 4;
-    SDE_CHECK_ARG(dxp && dx0 && B > 0 && H >= 3 && W >= 3 && C % V == 0, "sde_refl_fold: bad argument");
+    SDE_CHECK_ARG(dxp && dx0 && B > 0 && H >= 2 && W >= 2 && C % V == 0, "sde_refl_fold: bad argument (B=%d H=%d W=%d C=%d)", B, H, W, C);
     SDE_CHECK_ARG(!upcat || (C0 > 0 && C0 <= C && C0 % V == 0 && H % 2 == 0 && W % 2 == 0 && (C0 == C || dx1)), "sde_refl_fold: bad upcat argument");
     hipStream_t s = (hipStream_t)stream;
     const long items = upcat ? (long)B * (H / 2) * (W / 2) * (C0 / V) + (long)B * H * W * ((C - C0) / V) : (long)B * H * W * (C / V);

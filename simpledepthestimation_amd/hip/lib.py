@@ -43,6 +43,7 @@ _PROTOS = {
 }
 
 _lib = None
+PROFILE = None   # bench.py sets this to a list to collect (kind, flops, variant, start_event, end_event) per GEMM launch
 
 
 def register_protos(protos):

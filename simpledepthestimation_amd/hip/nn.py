@@ -25,6 +25,7 @@ L.register_protos({
     "sde_pack_weight": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
     "sde_conv_fwd": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P], c_int),
     "sde_conv_fwd_tiles_m": ([POINTER(ConvDesc), _I], c_int),
+    "sde_conv_fwd_variant": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_wgrad": ([POINTER(ConvDesc), _P, _I, _I, _I, _P, _I, _P, _I, _P], c_int),
     "sde_prep_input": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], c_int),
@@ -91,14 +92,28 @@ def _desc(x0, x1, src_mode, KH, KW, stride, pad, reflect, IH, IW, OH, OW):
     return d
 
 
-def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device):
+def _timed(kind, flops, variant, call):
+    """Run `call` bracketed by events on the current stream when L.PROFILE is a list (bench.py's roofline pass)."""
+    if L.PROFILE is None:
+        return call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = call()
+    e1.record()
+    L.PROFILE.append((kind, float(flops), variant, e0, e1))
+    return r
+
+
+def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device, kind="igemm_fwd", flops=0.0):
     y = torch.empty(d.Bn, d.OH, d.OW, ldy, device=device, dtype=x_dtype)
     stats, tiles = None, 0
     lib = L.lib()
     if want_stats:
         tiles = lib.sde_conv_fwd_tiles_m(ctypes.byref(d), ldy)
         stats = torch.empty(tiles, Cout, 2, device=device, dtype=torch.float32)
-    L.check(lib.sde_conv_fwd(ctypes.byref(d), L.ptr(w_packed), L.ptr(bias), act, L.ptr(y), Cout, ldy, L.ptr(stats), L.stream()), "sde_conv_fwd")
+    variant = lib.sde_conv_fwd_variant(ctypes.byref(d), ldy) if L.PROFILE is not None else 0
+    _timed(kind, flops, variant, lambda: L.check(lib.sde_conv_fwd(ctypes.byref(d), L.ptr(w_packed), L.ptr(bias), act, L.ptr(y), Cout, ldy, L.ptr(stats),
+                                                                  L.stream()), "sde_conv_fwd"))
     return y, stats
 
 
@@ -126,7 +141,8 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
         wp = pack_weight(weight, dt, C0 + C1, ldy)
         b32 = _f32(bias) if bias is not None else None
-        y, stats = conv_raw(d, dt, wp, b32, act, Cout, ldy, want_stats, x0.device)
+        flops = 2.0 * B * OH * OW * Cout * KH * KW * Cin          # algorithmic (real channels)
+        y, stats = conv_raw(d, dt, wp, b32, act, Cout, ldy, want_stats, x0.device, "igemm_fwd", flops)
         ctx.save_for_backward(x0, x1, weight, y if act != ACT_NONE else None)
         ctx.cfg = (stride, pad, reflect, act, upcat, bias is not None, IH, IW, OH, OW)
         if want_stats:
@@ -148,6 +164,7 @@ class _Conv2d(torch.autograd.Function):
         ldy = pad_to(Cout, V)
         dy = dy.contiguous()
         M = B * OH * OW
+        flops = 2.0 * M * Cout * KH * KW * Cin                    # algorithmic FLOPs of each of dgrad / wgrad
         # 1. activation backward + bias gradient
         dbias = None
         dz = dy
@@ -167,7 +184,8 @@ class _Conv2d(torch.autograd.Function):
             splits = lib.sde_conv_wgrad_splits(ctypes.byref(d), Cout)
             slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
             dw = torch.empty_like(weight)
-            L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw), 0, L.stream()), "sde_conv_wgrad")
+            _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw), 0,
+                                                                         L.stream()), "sde_conv_wgrad"))
         # 3. data gradient
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
@@ -175,7 +193,7 @@ class _Conv2d(torch.autograd.Function):
             wd = pack_weight(weight, dt, Cv, ldy, for_dgrad=True)          # [Cv][KH][KW][ldy], taps flipped
             if reflect:
                 dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1, False, OH, OW, IH + 2, IW + 2)
-                dxp, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev)
+                dxp, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
                 dx0 = torch.empty_like(x0)
                 dx1 = torch.empty_like(x1) if x1 is not None else None
                 L.check(lib.sde_refl_fold(L.ptr(dxp), B, IH, IW, Cv, C0, int(upcat), dtype_code(dt), L.ptr(dx0), L.ptr(dx1), L.stream()), "sde_refl_fold")
@@ -189,7 +207,7 @@ class _Conv2d(torch.autograd.Function):
                     dd = _desc(dz, None, SRC_ZEROINS, KH, KW, 1, KH - 1 - pad, False, 2 * OH - 1, 2 * OW - 1, IH, IW)
                 else:
                     raise L.SdeHipError(f"stride {stride} not supported")
-                dx0, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev)
+                dx0, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
         return dx0, dx1, dw, dbias, None, None, None, None, None, None
 
 

@@ -1,0 +1,140 @@
+"""CPU, world_size=2 over gloo: the data-parallel logic of engine.trainer.HipTrainer (flat buffers, initial broadcast, bucketed
+SUM all-reduce, 1/world inside the optimizer) reproduces single-process training on the concatenated batch.
+
+The model here is a tiny torch module (the HIP kernels need a GPU); the optimizer kernel is replaced by a torch restatement of
+sde_adam_step's update so the whole step runs on CPU.  What is under test is the N>1 control path, not the kernels.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def torch_adam(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corr, b1, b2, eps, grad_scale, decoupled):
+    start = 0
+    for s in range(seg_end.numel()):
+        end = int(seg_end[s]); lr = float(seg_lr[s]); wd = float(seg_wd[s])
+        gi = g[start:end] * grad_scale
+        pi = p[start:end]
+        if decoupled:
+            pi.mul_(1 - lr * wd)
+        else:
+            gi = gi + wd * pi
+        m[start:end].mul_(b1).add_(gi, alpha=1 - b1)
+        v[start:end].mul_(b2).addcmul_(gi, gi, value=1 - b2)
+        denom = v[start:end].sqrt() / float(bias_corr[1]) ** 0.5 + eps
+        pi.addcdiv_(m[start:end], denom, value=-lr / float(bias_corr[0]))
+        start = end
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(6, 5)
+        self.b = nn.Linear(5, 1)
+
+    def forward(self, batch):
+        y = self.b(torch.tanh(self.a(batch["x"]))).squeeze(-1)
+        return {"mse_loss": ((y - batch["t"]) ** 2).mean()}
+
+
+def _make(seed):
+    torch.manual_seed(seed)
+    return Tiny()
+
+
+def _trainer(model, world_aware=True):
+    from simpledepthestimation_amd.engine.trainer import HipTrainer, ParamGroup
+    groups = [ParamGroup("a", model.a.named_parameters(prefix="a"), 1e-2, 1e-2), ParamGroup("b", model.b.named_parameters(prefix="b"), 5e-3, 0.0)]
+    return HipTrainer(model, groups, adamw=True, eps=1e-6, bucket_mb=1e-5, adam_fn=torch_adam)    # tiny buckets -> several all-reduces
+
+
+def _data(n):
+    g = torch.Generator().manual_seed(99)
+    return torch.randn(n, 6, generator=g), torch.randn(n, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _make(10 + rank)                 # ranks start from DIFFERENT weights: the trainer must broadcast rank 0's
+        tr = _trainer(model)
+        assert len(tr.buckets) > 1
+        x, t = _data(8)
+        half = slice(rank * 4, rank * 4 + 4)
+        for _ in range(3):
+            tr.step({"x": x[half], "t": t[half]})
+        out[rank] = tr.pflat.clone()
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_dp2_matches_single_process():
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        p0, p1 = out[0], out[1]
+    assert torch.equal(p0, p1), "ranks diverged"
+    # single process on the full batch with the same initial weights (rank 0's) must give the same parameters:
+    # mean over 8 samples == (mean over 4 + mean over 4) / 2  == SUM all-reduce * 1/world
+    model = _make(10)
+    tr = _trainer(model)
+    x, t = _data(8)
+    for _ in range(3):
+        tr.step({"x": x, "t": t})
+    assert torch.allclose(tr.pflat, p0, rtol=1e-5, atol=1e-7)
+
+
+def test_flat_views_alias_parameters():
+    model = _make(0)
+    tr = _trainer(model)
+    n = sum(p.numel() for p in model.parameters())
+    assert tr.numel == n and tr.pflat.numel() == n
+    for p in model.parameters():
+        assert p.data.data_ptr() >= tr.pflat.data_ptr() and p.data.data_ptr() < tr.pflat.data_ptr() + 4 * n
+        assert p.grad.data_ptr() >= tr.gflat.data_ptr() and p.grad.data_ptr() < tr.gflat.data_ptr() + 4 * n
+    x, t = _data(4)
+    before = tr.pflat.clone()
+    tr.step({"x": x, "t": t})
+    assert not torch.equal(before, tr.pflat)
+    assert torch.equal(model.a.weight.data.reshape(-1), tr.pflat[:30])
+
+
+def test_optimizer_matches_torch_adamw():
+    model, ref = _make(3), _make(3)
+    tr = _trainer(model)
+    opt = torch.optim.AdamW([{"params": ref.a.parameters(), "lr": 1e-2, "weight_decay": 1e-2}, {"params": ref.b.parameters(), "lr": 5e-3, "weight_decay": 0.0}],
+                            eps=1e-6)
+    x, t = _data(8)
+    for _ in range(4):
+        tr.step({"x": x, "t": t})
+        opt.zero_grad(); ref({"x": x, "t": t})["mse_loss"].backward(); opt.step()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
+
+
+def test_lr_schedules():
+    from simpledepthestimation_amd.config import get_cfg
+    from simpledepthestimation_amd.engine.trainer import multistep_lr, poly_lr
+    cfg = get_cfg()
+    cfg.SOLVER.DEPTH_LR, cfg.SOLVER.DEPTH_END_LR = 1e-4, 1e-5
+    assert abs(poly_lr(cfg, 0, 100) - 1e-4) < 1e-12 and abs(poly_lr(cfg, 100, 100) - 1e-5) < 1e-12
+    assert abs(poly_lr(cfg, 50, 100) - ((1e-4 - 1e-5) * 0.5 ** 0.9 + 1e-5)) < 1e-12
+    assert multistep_lr(2e-4, 14, (15,), 0.1) == 2e-4 and abs(multistep_lr(2e-4, 15, (15,), 0.1) - 2e-5) < 1e-12
