@@ -79,7 +79,15 @@ def roofline_pass(trainer, batch, steps, dtype):
     torch.cuda.synchronize()
     recs, L.PROFILE = L.PROFILE, None
     fam = {}
-    for kind, flops, variant, e0, e1 in recs:
+    if os.environ.get("SDE_BENCH_LAYER_DUMP"):
+        with open(os.environ["SDE_BENCH_LAYER_DUMP"], "w") as f:
+            f.write("kind,variant,M,N,K,k,stride,mode,splits,us,tflops,unique_GBps\n")
+            for kind, flops, variant, e0, e1, meta in recs[:len(recs) // steps]:
+                us = e0.elapsed_time(e1) * 1e3
+                m = meta or {}
+                f.write(f"{kind},{variant},{m.get('M')},{m.get('N')},{m.get('K')},{m.get('k')},{m.get('s')},{m.get('mode')},{m.get('splits', '')},"
+                        f"{us:.1f},{flops / us / 1e6:.1f},{m.get('bytes', 0) / us / 1e3:.0f}\n")
+    for kind, flops, variant, e0, e1, _meta in recs:
         key = ("igemm" if kind.startswith("igemm") else kind, variant)
         f = fam.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
         f["ms"] += e0.elapsed_time(e1); f["flops"] += flops; f["launches"] += 1

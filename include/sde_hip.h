@@ -29,6 +29,10 @@ typedef void* sde_stream_t; /* hipStream_t */
 #define SDE_F32 0
 #define SDE_BF16 1
 
+/* Partial-sum slabs (BatchNorm statistics, BN/bias backward reductions) must be allocated with SDE_REDUCE_ROWS extra rows:
+ * slabs taller than that are first folded into their own tail by a deterministic two-level reduction. */
+#define SDE_REDUCE_ROWS 32
+
 #define SDE_RESIZE_BILINEAR_AC 0 /* F.interpolate(mode='bilinear', align_corners=True) */
 #define SDE_RESIZE_NEAREST 1     /* F.interpolate(mode='nearest') */
 
@@ -131,7 +135,7 @@ int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int
 /* y[Bn,OH,OW,ldy] = act(conv(virtual input, w_packed) + bias); channels >= Cout of y are written as zeros.
  * Replaces nn.Conv2d (+ReflectionPad2d, +upsample/cat, +nn.ELU) forward -- resnet_encoder.py:L91-97, depth_decoder.py:L21-53,
  * PoseNet.py:L13-16 -- and, with the flipped operand of sde_pack_weight(for_dgrad=1), their data-gradient.
- * stats (optional): [sde_conv_fwd_tiles_m][Cout][2] per-tile (sum, sum of squares) of the stored outputs, for BatchNorm. */
+ * stats (optional): [sde_conv_fwd_tiles_m + SDE_REDUCE_ROWS][Cout][2] per-tile (sum, sum of squares) of the stored outputs, for BatchNorm. */
 int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
                  sde_stream_t stream);
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy);
@@ -159,7 +163,7 @@ int sde_bn_eval_params(const float* gamma, const float* beta, const float* runni
                        sde_stream_t stream);
 /* out = [relu](y*scale + shift [+ residual]) */
 int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu, long M, int C, int dtype, void* out, sde_stream_t stream);
-/* BatchNorm(+ReLU, +residual) backward.  part: [sde_reduce_num_blocks(M)][C][2] workspace, coef: [2][C] workspace.
+/* BatchNorm(+ReLU, +residual) backward.  part: [sde_reduce_num_blocks(M) + SDE_REDUCE_ROWS][C][2] workspace, coef: [2][C] workspace.
  * dy [M,C]; dres (optional) [M,C] = gradient of the residual input; dgamma/dbeta [C] (+)=. */
 int sde_reduce_num_blocks(long M);
 int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, const float* gamma, int relu, long M, int C, int dtype, float* part,
@@ -170,7 +174,7 @@ int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* 
 int sde_maxpool_bwd(const void* dout, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream);
 
 /* dz = dout * act'(out) (nn.ELU / nn.ReLU backward) fused with the bias gradient dbias[c] (+)= sum_rows dz[:, c], c < Cbias.
- * dz and/or dbias may be NULL; part: [sde_reduce_num_blocks(M)][C] workspace (needed when dbias != NULL). */
+ * dz and/or dbias may be NULL; part: [sde_reduce_num_blocks(M) + SDE_REDUCE_ROWS][C] workspace (needed when dbias != NULL). */
 int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias, int accumulate,
                      sde_stream_t stream);
 

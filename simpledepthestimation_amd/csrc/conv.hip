@@ -448,18 +448,26 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(WGradP p) {
             }
 }
 
-// Sum the slabs in fixed order and scatter into the master OIHW fp32 gradient (skipping padded input channels).
+// Sum the slabs in fixed order and write the master OIHW fp32 gradient (skipping padded input channels).
+// One workgroup per output channel: the K-major sums go through LDS so that both the slab reads and the OIHW writes are
+// contiguous (the [tap][ci] -> [ci][tap] transpose happens in LDS).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int KHW, int Cin_pad,
                                                            int Cin_real, float* __restrict__ dw, int accumulate) {
-    const size_t total = (size_t)Cout * KHW * Cin_pad;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int ci = (int)(i % Cin_pad);
-        if (ci >= Cin_real) continue;
-        const int tap = (int)((i / Cin_pad) % KHW), co = (int)(i / ((size_t)Cin_pad * KHW));
+    extern __shared__ float sk[];   // [KHW * Cin_pad]
+    const int co = blockIdx.x, K = KHW * Cin_pad;
+    const size_t total = (size_t)Cout * K;
+    for (int k = threadIdx.x; k < K; k += 256) {
         float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + i];
-        float* o = dw + ((size_t)co * Cin_real + ci) * KHW + tap;
-        *o = accumulate ? *o + s : s;
+        for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + (size_t)co * K + k];
+        sk[k] = s;
+    }
+    __syncthreads();
+    const int n = Cin_real * KHW;
+    float* o = dw + (size_t)co * n;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const int ci = j / KHW, tap = j - ci * KHW;
+        const float v = sk[tap * Cin_pad + ci];
+        o[j] = accumulate ? o[j] + v : v;
     }
 }
 
@@ -618,7 +626,7 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     const int Ktot = d->KH * d->KW * (d->C0 + d->C1);
     const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, 128);
     const int BR = d->dtype == SDE_BF16 ? 64 : 32;
-    long want = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU
+    long want = (512 + tiles - 1) / tiles;                  // ~2 workgroups per CU
     const long max_by_rows = (M + 4 * BR - 1) / (4 * BR);   // at least 4 stages per split
     if (want > max_by_rows) want = max_by_rows;
     const long max_by_mem = (256L << 20) / ((long)Cout * Ktot * 4);   // slab <= 256 MiB
@@ -645,9 +653,14 @@ int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, in
     if (d->dtype == SDE_BF16) dispatch_wgrad<bf16_t>(p, splits, s);
     else dispatch_wgrad<float>(p, splits, s);
     SDE_CHECK_LAUNCH("sde_conv_wgrad");
-    const size_t total = (size_t)Cout * p.g.Ktot;
-    const int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, slab, splits, Cout, d->KH * d->KW, p.g.Cin, Cin_real, dw, accumulate);
+    const size_t lds_red = (size_t)p.g.Ktot * sizeof(float);
+    SDE_CHECK_ARG(lds_red <= 160 * 1024, "sde_conv_wgrad: K=%d too large for the reduce kernel's LDS transpose", p.g.Ktot);
+    static bool red_attr = false;
+    if (!red_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        red_attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), lds_red, s, slab, splits, Cout, d->KH * d->KW, p.g.Cin, Cin_real, dw, accumulate);
     SDE_CHECK_LAUNCH("sde_conv_wgrad/reduce");
     return SDE_OK;
 }

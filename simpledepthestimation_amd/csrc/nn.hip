@@ -68,6 +68,27 @@ __global__ void __launch_bounds__(256) prep_input_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Deterministic two-level reduction of partial-sum slabs: out[ro][col] = sum of rows of chunk ro of in[rows][width].
+// The small second level (<= SDE_REDUCE_ROWS rows) is summed in fp64 by the *_finalize kernels.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) rows_reduce_kernel(const float* __restrict__ in, int rows, int width, int chunk, float* __restrict__ out) {
+    __shared__ float sh[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, ro = blockIdx.y;
+    const int r0 = ro * chunk, r1 = min(rows, r0 + chunk);
+    float s = 0.f;
+    if (col < width)
+        for (int r = r0 + sub; r < r1; r += 16) s += in[(size_t)r * width + col];
+    sh[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && col < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][threadIdx.x & 63];
+        out[(size_t)ro * width + col] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // BatchNorm
 // ------------------------------------------------------------------------------------------------------------------
 // bnp layout: [4][C] = mean, rstd, scale (= gamma*rstd), shift (= beta - mean*scale)
@@ -632,6 +653,18 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// If the slab has more than SDE_REDUCE_ROWS rows, fold it into SDE_REDUCE_ROWS rows stored right behind it (the caller
+// allocates rows + SDE_REDUCE_ROWS rows).  Returns the pointer / row count the finalize kernel should read.
+const float* pre_reduce(const float* part, int& rows, int width, hipStream_t s) {
+    if (rows <= SDE_REDUCE_ROWS) return part;
+    float* out = const_cast<float*>(part) + (size_t)rows * width;
+    const int chunk = (rows + SDE_REDUCE_ROWS - 1) / SDE_REDUCE_ROWS;
+    const int rows_out = (rows + chunk - 1) / chunk;
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((width + 63) / 64, rows_out), dim3(1024), 0, s, part, rows, width, chunk, out);
+    rows = rows_out;
+    return out;
+}
+
 int grid_for(long n_items) {
     long nb = (n_items + 255) / 256;
     if (nb < 1) nb = 1;
@@ -664,7 +697,9 @@ int sde_prep_input(const float* img, const float* mean, const float* std_, int B
 int sde_bn_finalize(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float momentum, float eps, float* bnp, sde_stream_t stream) {
     SDE_CHECK_ARG(part && gamma && beta && bnp && tiles > 0 && C > 0 && count > 0, "sde_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, part, tiles, C, (float)count, gamma, beta, running_mean,
+    int rows = tiles;
+    const float* src = pre_reduce(part, rows, 2 * C, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, src, rows, C, (float)count, gamma, beta, running_mean,
                        running_var, momentum, eps, bnp);
     SDE_CHECK_LAUNCH("sde_bn_finalize");
     return SDE_OK;
@@ -691,7 +726,7 @@ int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu
 
 int sde_reduce_num_blocks(long M) {
     long nb = (M + 255) / 256;     // >= 256 rows per block
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -710,7 +745,9 @@ int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bn
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)y, bnp, relu, M, C, rpb, part),
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part));
     SDE_CHECK_LAUNCH("sde_bn_bwd/reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, s, part, nblk, C, (float)M, dgamma, dbeta, accumulate_params, coef);
+    int rows = nblk;
+    const float* src = pre_reduce(part, rows, 2 * C, s);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, s, src, rows, C, (float)M, dgamma, dbeta, accumulate_params, coef);
     SDE_CHECK_LAUNCH("sde_bn_bwd/finalize");
     const int nb = grid_for(M * (C / V));
     DISPATCH_T(dtype,
@@ -760,7 +797,9 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
                hipLaunchKernelGGL(act_bwd_bias_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, act, M, C, rpb, (bf16_t*)dz, p));
     SDE_CHECK_LAUNCH("sde_act_bwd_bias");
     if (dbias) {
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sde_cdiv(Cbias, 64)), dim3(64), 0, s, part, nblk, C, Cbias, dbias, accumulate);
+        int rows = nblk;
+        const float* src = pre_reduce(part, rows, C, s);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sde_cdiv(Cbias, 64)), dim3(64), 0, s, src, rows, C, Cbias, dbias, accumulate);
         SDE_CHECK_LAUNCH("sde_act_bwd_bias/finalize");
     }
     return SDE_OK;

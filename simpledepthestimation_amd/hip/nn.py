@@ -11,6 +11,7 @@ import torch
 from . import lib as L
 
 SRC_PLAIN, SRC_UPCAT, SRC_ZEROINS = 0, 1, 2
+REDUCE_ROWS = 32   # SDE_REDUCE_ROWS: scratch rows every partial-sum slab carries behind its payload
 ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 
 
@@ -62,6 +63,15 @@ def pad_to(c, v):
     return (c + v - 1) // v * v
 
 
+def _grad_slot(p):
+    """A parameter's pre-allocated fp32 .grad (HipTrainer points it into the flat gradient buffer): kernels then accumulate
+    straight into it and the Function returns None for that input, which skips autograd's per-parameter add kernel."""
+    g = p.grad if (p is not None and p.is_leaf) else None
+    if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape:
+        return g
+    return None
+
+
 def _f32(t):
     if t.dtype != torch.float32:
         raise L.SdeHipError("parameters must be float32")
@@ -92,7 +102,7 @@ def _desc(x0, x1, src_mode, KH, KW, stride, pad, reflect, IH, IW, OH, OW):
     return d
 
 
-def _timed(kind, flops, variant, call):
+def _timed(kind, flops, variant, call, meta=None):
     """Run `call` bracketed by events on the current stream when L.PROFILE is a list (bench.py's roofline pass)."""
     if L.PROFILE is None:
         return call()
@@ -100,7 +110,7 @@ def _timed(kind, flops, variant, call):
     e0.record()
     r = call()
     e1.record()
-    L.PROFILE.append((kind, float(flops), variant, e0, e1))
+    L.PROFILE.append((kind, float(flops), variant, e0, e1, meta))
     return r
 
 
@@ -110,10 +120,15 @@ def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device, kin
     lib = L.lib()
     if want_stats:
         tiles = lib.sde_conv_fwd_tiles_m(ctypes.byref(d), ldy)
-        stats = torch.empty(tiles, Cout, 2, device=device, dtype=torch.float32)
+        stats = torch.empty(tiles + REDUCE_ROWS, Cout, 2, device=device, dtype=torch.float32)
     variant = lib.sde_conv_fwd_variant(ctypes.byref(d), ldy) if L.PROFILE is not None else 0
+    meta = None
+    if L.PROFILE is not None:
+        esz = 2 if x_dtype == torch.bfloat16 else 4
+        meta = dict(M=d.Bn * d.OH * d.OW, N=ldy, K=d.KH * d.KW * (d.C0 + d.C1), k=d.KH, s=d.stride, mode=d.src_mode,
+                    bytes=esz * (d.Bn * d.H0 * d.W0 * d.C0 + d.Bn * d.IH * d.IW * d.C1 + d.Bn * d.OH * d.OW * ldy))
     _timed(kind, flops, variant, lambda: L.check(lib.sde_conv_fwd(ctypes.byref(d), L.ptr(w_packed), L.ptr(bias), act, L.ptr(y), Cout, ldy, L.ptr(stats),
-                                                                  L.stream()), "sde_conv_fwd"))
+                                                                  L.stream()), "sde_conv_fwd"), meta)
     return y, stats
 
 
@@ -144,6 +159,7 @@ class _Conv2d(torch.autograd.Function):
         flops = 2.0 * B * OH * OW * Cout * KH * KW * Cin          # algorithmic (real channels)
         y, stats = conv_raw(d, dt, wp, b32, act, Cout, ldy, want_stats, x0.device, "igemm_fwd", flops)
         ctx.save_for_backward(x0, x1, weight, y if act != ACT_NONE else None)
+        ctx.params = (weight, bias)
         ctx.cfg = (stride, pad, reflect, act, upcat, bias is not None, IH, IW, OH, OW)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -170,11 +186,14 @@ class _Conv2d(torch.autograd.Function):
         dz = dy
         if act != ACT_NONE or has_bias:
             nblk = lib.sde_reduce_num_blocks(M)
-            part = torch.empty(nblk, ldy, device=dev) if has_bias else None
-            dbias = torch.empty(Cout, device=dev) if has_bias else None
+            part = torch.empty(nblk + REDUCE_ROWS, ldy, device=dev) if has_bias else None
+            bslot = _grad_slot(ctx.params[1]) if has_bias else None
+            dbias = (bslot if bslot is not None else torch.empty(Cout, device=dev)) if has_bias else None
             dz = torch.empty_like(dy) if act != ACT_NONE else None
-            L.check(lib.sde_act_bwd_bias(L.ptr(dy), L.ptr(y), act, M, ldy, dtype_code(dt), L.ptr(dz), L.ptr(part), L.ptr(dbias), Cout, 0, L.stream()),
-                    "sde_act_bwd_bias")
+            L.check(lib.sde_act_bwd_bias(L.ptr(dy), L.ptr(y), act, M, ldy, dtype_code(dt), L.ptr(dz), L.ptr(part), L.ptr(dbias), Cout,
+                                         int(bslot is not None), L.stream()), "sde_act_bwd_bias")
+            if bslot is not None:
+                dbias = None
             if dz is None:
                 dz = dy
         # 2. weight gradient
@@ -183,9 +202,17 @@ class _Conv2d(torch.autograd.Function):
             d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
             splits = lib.sde_conv_wgrad_splits(ctypes.byref(d), Cout)
             slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
-            dw = torch.empty_like(weight)
-            _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw), 0,
-                                                                         L.stream()), "sde_conv_wgrad"))
+            wslot = _grad_slot(ctx.params[0])
+            dw = wslot if wslot is not None else torch.empty_like(weight)
+            meta = None
+            if L.PROFILE is not None:
+                esz = 2 if dt == torch.bfloat16 else 4
+                meta = dict(M=M, N=Cout, K=KH * KW * (C0 + C1), k=KH, s=stride, mode=int(upcat), splits=splits,
+                            bytes=esz * (B * H0 * W0 * C0 + B * IH * IW * C1 + M * ldy) + 8 * splits * Cout * KH * KW * (C0 + C1))
+            _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
+                                                                         int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
+            if wslot is not None:
+                dw = None
         # 3. data gradient
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
@@ -233,7 +260,7 @@ class _BatchNormAct(torch.autograd.Function):
         dev = y.device
         bnp = torch.empty(4, C, device=dev)
         if training:
-            L.check(lib.sde_bn_finalize(L.ptr(stats), stats.shape[0], C, M, L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var),
+            L.check(lib.sde_bn_finalize(L.ptr(stats), stats.shape[0] - REDUCE_ROWS, C, M, L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var),
                                         momentum, eps, L.ptr(bnp), L.stream()), "sde_bn_finalize")
         else:
             L.check(lib.sde_bn_eval_params(L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var), eps, C, L.ptr(bnp), L.stream()),
@@ -241,6 +268,7 @@ class _BatchNormAct(torch.autograd.Function):
         out = torch.empty_like(y)
         L.check(lib.sde_bn_apply(L.ptr(y), L.ptr(bnp), L.ptr(residual), int(relu), M, C, dtype_code(dt), L.ptr(out), L.stream()), "sde_bn_apply")
         ctx.save_for_backward(y, out if relu else None, bnp, gamma)
+        ctx.params = (gamma, beta)
         ctx.cfg = (relu, residual is not None, training)
         return out
 
@@ -256,14 +284,18 @@ class _BatchNormAct(torch.autograd.Function):
         lib = L.lib()
         dev = y.device
         dout = dout.contiguous()
-        part = torch.empty(lib.sde_reduce_num_blocks(M), C, 2, device=dev)
+        part = torch.empty(lib.sde_reduce_num_blocks(M) + REDUCE_ROWS, C, 2, device=dev)
         coef = torch.empty(2, C, device=dev)
-        dgamma = torch.empty(C, device=dev)
-        dbeta = torch.empty(C, device=dev)
+        gs, bs = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+        direct = gs is not None and bs is not None
+        dgamma = gs if direct else torch.empty(C, device=dev)
+        dbeta = bs if direct else torch.empty(C, device=dev)
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
         L.check(lib.sde_bn_bwd(L.ptr(dout), L.ptr(out), L.ptr(y), L.ptr(bnp), L.ptr(gamma), int(relu), M, C, dtype_code(dt), L.ptr(part), L.ptr(coef),
-                               L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dy), L.ptr(dres), L.stream()), "sde_bn_bwd")
+                               L.ptr(dgamma), L.ptr(dbeta), int(direct), L.ptr(dy), L.ptr(dres), L.stream()), "sde_bn_bwd")
+        if direct:
+            dgamma = dbeta = None
         return dy, None, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
@@ -357,6 +389,7 @@ class _GroupNormReLU(torch.autograd.Function):
         L.check(L.lib().sde_gn_relu_fwd(L.ptr(x.contiguous()), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), B, H * W, C, groups, eps, int(relu), dtype_code(x.dtype),
                                         L.ptr(part), L.ptr(gnp), L.ptr(out), L.stream()), "sde_gn_relu_fwd")
         ctx.save_for_backward(x, out, gnp, gamma)
+        ctx.params = (gamma, beta)
         ctx.cfg = (groups, relu)
         return out
 
@@ -368,11 +401,16 @@ class _GroupNormReLU(torch.autograd.Function):
         dev = x.device
         part = torch.empty(B, 16, C, 2, device=dev)
         coef = torch.empty(B, groups, 2, device=dev)
-        dgamma = torch.empty(C, device=dev)
-        dbeta = torch.empty(C, device=dev)
+        gs, bs = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+        direct = gs is not None and bs is not None
+        dgamma = gs if direct else torch.empty(C, device=dev)
+        dbeta = bs if direct else torch.empty(C, device=dev)
         dx = torch.empty_like(x)
         L.check(L.lib().sde_gn_relu_bwd(L.ptr(dout.contiguous()), L.ptr(out), L.ptr(x), L.ptr(gnp), L.ptr(_f32(gamma)), B, H * W, C, groups, int(relu),
-                                        dtype_code(x.dtype), L.ptr(part), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), 0, L.ptr(dx), L.stream()), "sde_gn_relu_bwd")
+                                        dtype_code(x.dtype), L.ptr(part), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), int(direct), L.ptr(dx), L.stream()),
+                "sde_gn_relu_bwd")
+        if direct:
+            dgamma = dbeta = None
         return dx, dgamma, dbeta, None, None, None
 
 

@@ -46,10 +46,20 @@ class HipBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending_batches = 0     # counted on the host, folded into the buffer when the state dict is read (no per-layer kernel)
+
+    def flush_counters(self):
+        if self._pending_batches:
+            self.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_counters()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def forward(self, y, stats, residual=None, relu=True):
         if self.training:
-            self.num_batches_tracked.add_(1)
+            self._pending_batches += 1
         return HN.batch_norm_act(y, stats, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.momentum, self.eps,
                                  self.training)
 
