@@ -132,6 +132,16 @@ typedef struct sde_conv_desc {
 int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cin_pad, int Cout_pad, int for_dgrad,
                     sde_stream_t stream);
 
+/* The same for every layer of a model in ONE launch (the weights change once per optimizer step).  items: DEVICE array of n jobs;
+ * `end` = exclusive prefix sum of the jobs' output element counts, total = items[n-1].end. */
+typedef struct sde_pack_item {
+    const float* src; /* master OIHW fp32 */
+    void* dst;        /* packed operand in `dtype` */
+    int32_t Cout, Cin, KH, KW, Cin_pad, Cout_pad, for_dgrad, reserved;
+    int64_t end;
+} sde_pack_item;
+int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total, int dtype, sde_stream_t stream);
+
 /* y[Bn,OH,OW,ldy] = act(conv(virtual input, w_packed) + bias); channels >= Cout of y are written as zeros.
  * Replaces nn.Conv2d (+ReflectionPad2d, +upsample/cat, +nn.ELU) forward -- resnet_encoder.py:L91-97, depth_decoder.py:L21-53,
  * PoseNet.py:L13-16 -- and, with the flipped operand of sde_pack_weight(for_dgrad=1), their data-gradient.
@@ -142,7 +152,9 @@ int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy);
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy); /* tile the dispatcher picks: BM*1000 + BN (profiling aid) */
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).
- * slab: caller workspace [splits][Cout][KH*KW*(C0+C1)] fp32, splits = sde_conv_wgrad_splits(d, Cout). */
+ * slab: caller workspace [splits + SDE_WGRAD_FOLD_ROWS][Cout][KH*KW*(C0+C1)] fp32, splits = sde_conv_wgrad_splits(d, Cout)
+ * (the extra rows are scratch for folding tall slab stacks before the final fixed-order sum). */
+#define SDE_WGRAD_FOLD_ROWS 16
 int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout);
 int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, int Cin_real, float* slab, int splits, float* dw, int accumulate,
                    sde_stream_t stream);

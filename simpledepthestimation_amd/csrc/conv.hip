@@ -71,6 +71,15 @@ __device__ __forceinline__ uint4 gather16(const Gather& g, int n, int ih, int iw
     return *reinterpret_cast<const uint4*>(src);
 }
 
+// XCD-aware work order (8 XCDs, each with a private L2; workgroups are dealt round-robin over the XCDs): remap the linear
+// block id so that every XCD walks one CONTIGUOUS range of logical tiles.  Neighbouring tiles share halo rows, filter taps and
+// the A rows of all N tiles, so those re-reads become hits in that XCD's L2 instead of refills from beyond it.  Bijective
+// for any grid size; placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // MFMA wrappers: one 64-byte K sub-block (32 bf16 / 16 f32) of a 16x16 fragment pair
 // ------------------------------------------------------------------------------------------------------------------
@@ -109,15 +118,30 @@ struct IGemmP {
 constexpr int KSTAGE_BYTES = 128;   // K bytes per row per pipeline stage (2 MFMA sub-blocks of 64 B)
 constexpr int NTHREADS = 256;
 
+// Address of the 16-byte group (n, ih, iw, ci) of the virtual input, or nullptr when it is padding / an inserted zero.
+template <typename T>
+__device__ __forceinline__ const T* gather_ptr(const Gather& g, int n, int ih, int iw, int ci) {
+    if (g.reflect) { ih = reflect1(ih, g.IH); iw = reflect1(iw, g.IW); }
+    else if ((unsigned)ih >= (unsigned)g.IH || (unsigned)iw >= (unsigned)g.IW) return nullptr;
+    if (g.mode == SDE_SRC_PLAIN) return (const T*)g.x0 + ((size_t)((n * g.H0 + ih) * g.W0 + iw)) * g.C0 + ci;
+    if (g.mode == SDE_SRC_UPCAT) {
+        if (ci < g.C0) return (const T*)g.x0 + ((size_t)((n * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1))) * g.C0 + ci;
+        return (const T*)g.x1 + ((size_t)((n * g.IH + ih) * g.IW + iw)) * g.C1 + (ci - g.C0);
+    }
+    if ((ih | iw) & 1) return nullptr;
+    return (const T*)g.x0 + ((size_t)((n * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1))) * g.C0 + ci;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(NTHREADS) igemm_kernel(IGemmP p) {
     constexpr int V = VecOf<T>::V;
     constexpr int BK = KSTAGE_BYTES / (int)sizeof(T);
     constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile
     constexpr int FM = WTM / 16, FN = WTN / 16;
-    constexpr int A_ROWS_PER_PASS = NTHREADS / 8;   // 8 chunks of 16 B per row
-    constexpr int A_PASSES = BM / A_ROWS_PER_PASS;
-    constexpr int B_PASSES = (BN + A_ROWS_PER_PASS - 1) / A_ROWS_PER_PASS;
+    constexpr int TPR = NTHREADS / BM;              // threads per A row (2 or 4): each owns CPT consecutive 16-byte chunks
+    constexpr int CPT = 8 / TPR;
+    constexpr int B_ROWS_PER_PASS = NTHREADS / 8;   // B tile: 8 chunks of 16 B per row, 32 rows per pass
+    constexpr int B_PASSES = (BN + B_ROWS_PER_PASS - 1) / B_ROWS_PER_PASS;
     constexpr int CPAD = 4;
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -127,42 +151,58 @@ __global__ void __launch_bounds__(NTHREADS) igemm_kernel(IGemmP p) {
     const Gather& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile_m = blockIdx.x, tile_n = blockIdx.y;
+    const int tiles_n = (p.ldy + BN - 1) / BN;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;     // N tiles of one M tile are adjacent in time, on one XCD
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int cc = tid & 7;            // 16-byte chunk column inside the stage
-    const int r0 = tid >> 3;           // first row handled by this thread
 
-    // per-row output-pixel decomposition (fixed for the whole K loop)
-    int rn[A_PASSES], rih[A_PASSES], riw[A_PASSES];
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-        const int m = m0 + r0 + i * A_ROWS_PER_PASS;
+    // ---- A side: this thread gathers chunks [ac0, ac0+CPT) of tile row `arow` in every stage.
+    // Output-pixel decomposition happens once; the (tap, channel) position of the first chunk is advanced incrementally.
+    const int arow = tid / TPR, ac0 = (tid % TPR) * CPT;
+    int an = -1, aih = 0, aiw = 0;
+    {
+        const int m = m0 + arow;
         if (m < g.M) {
-            const int n = m / (g.OH * g.OW);
-            const int rem = m - n * (g.OH * g.OW);
+            an = m / (g.OH * g.OW);
+            const int rem = m - an * (g.OH * g.OW);
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            rn[i] = n; rih[i] = oh * g.stride - g.pad; riw[i] = ow * g.stride - g.pad;
-        } else {
-            rn[i] = -1; rih[i] = 0; riw[i] = 0;
+            aih = oh * g.stride - g.pad; aiw = ow * g.stride - g.pad;
         }
     }
+    int aci, akh, akw;     // position of chunk ac0 of the NEXT stage to load
+    {
+        const int k = ac0 * V;
+        const int tap = k / g.Cin;
+        aci = k - tap * g.Cin; akh = tap / g.KW; akw = tap - akh * g.KW;
+    }
+    // ---- B side (weights, plain 2-D): rows r0 + 32 i, chunk column cc
+    const int cc = tid & 7, r0 = tid >> 3;
     const int nk = (g.Ktot + BK - 1) / BK;
-    uint4 ra[A_PASSES], rb[B_PASSES];
+    uint4 ra[CPT], rb[B_PASSES];
 
     auto load_stage = [&](int s) {
+        int ci = aci, kh = akh, kw = akw;
+        const T* ptr = nullptr;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (an >= 0 && kh < g.KH) {
+                if (c == 0 || ci == 0 || (g.mode == SDE_SRC_UPCAT && ci == g.C0)) ptr = gather_ptr<T>(g, an, aih + kh, aiw + kw, ci);
+                else if (ptr) ptr += V;
+                if (ptr) v = *reinterpret_cast<const uint4*>(ptr);
+            }
+            ra[c] = v;
+            ci += V;
+            if (ci == g.Cin) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+        }
+        // advance the thread's base position by one stage (BK elements)
+        aci += BK;
+        while (aci >= g.Cin) { aci -= g.Cin; if (++akw == g.KW) { akw = 0; ++akh; } }
         const int k = s * BK + cc * V;
         const bool kok = k < g.Ktot;
-        const int tap = k / g.Cin, ci = k - tap * g.Cin;
-        const int kh = tap / g.KW, kw = tap - kh * g.KW;
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (kok && rn[i] >= 0) v = gather16<T>(g, rn[i], rih[i] + kh, riw[i] + kw, ci);
-            ra[i] = v;
-        }
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
-            const int row = r0 + i * A_ROWS_PER_PASS;
+            const int row = r0 + i * B_ROWS_PER_PASS;
             const int n = n0 + row;
             uint4 v = {0u, 0u, 0u, 0u};
             if (kok && row < BN && n < p.Cout) v = *reinterpret_cast<const uint4*>((const T*)p.w + (size_t)n * g.Ktot + k);
@@ -171,13 +211,11 @@ __global__ void __launch_bounds__(NTHREADS) igemm_kernel(IGemmP p) {
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            const int row = r0 + i * A_ROWS_PER_PASS;
-            *reinterpret_cast<uint4*>(sA + (size_t)(buf * BM + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = ra[i];
-        }
+        for (int c = 0; c < CPT; ++c)
+            *reinterpret_cast<uint4*>(sA + (size_t)(buf * BM + arow) * KSTAGE_BYTES + (((ac0 + c) ^ (arow & 7)) << 4)) = ra[c];
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
-            const int row = r0 + i * A_ROWS_PER_PASS;
+            const int row = r0 + i * B_ROWS_PER_PASS;
             if (row < BN) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = rb[i];
         }
     };
@@ -337,10 +375,12 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(WGradP p) {
     constexpr int FM = WTM / 16, FN = WTN / 16;
     constexpr int STRA = BMG * (int)sizeof(T) + 16;    // padded LDS row strides (bytes)
     constexpr int STRB = BNG * (int)sizeof(T) + 16;
-    constexpr int ACH = BMG / V, BCH = BNG / V;        // 16-byte chunks per row
-    constexpr int A_PASSES = (BR * ACH + NTHREADS - 1) / NTHREADS;
-    constexpr int B_PASSES = (BR * BCH + NTHREADS - 1) / NTHREADS;
+    constexpr int ACH = BMG / V, BCH = BNG / V;        // 16-byte chunks per pixel row
+    constexpr int TPP = NTHREADS / BR;                 // threads per pixel row (4 bf16 / 8 f32)
+    constexpr int CPTB = BCH / TPP;                    // B chunks per thread (4)
+    constexpr int CPTA = (ACH + TPP - 1) / TPP;        // A chunks per thread (<= 4)
     static_assert(WM * WN == 4, "4 waves");
+    static_assert(BCH % TPP == 0, "B tile chunking");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                          // [2][BR][STRA]
     unsigned char* sB = smem + 2 * BR * STRA;          // [2][BR][STRB]
@@ -348,59 +388,66 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(WGradP p) {
     const Gather& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int co0 = blockIdx.x * BMG, k0 = blockIdx.y * BNG, split = blockIdx.z;
+    const int tiles_co = (p.Cout + BMG - 1) / BMG, tiles_k = (g.Ktot + BNG - 1) / BNG;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / (tiles_co * tiles_k), rem_t = logical - split * (tiles_co * tiles_k);
+    const int co0 = (rem_t % tiles_co) * BMG, k0 = (rem_t / tiles_co) * BNG;       // all tiles of one pixel range run together on one XCD
     const int mbeg = split * p.rows_per_split, mend = min(g.M, mbeg + p.rows_per_split);
 
-    // B-side (im2col of X) column info is fixed per thread: chunk column -> (tap, ci)
-    int bkh[B_PASSES], bkw[B_PASSES], bci[B_PASSES], bpx[B_PASSES], bcol[B_PASSES];
+    // Each thread owns pixel row `px` of every stage and fixed chunk columns: the im2col column -> (tap, ci) map is
+    // computed once; the pixel -> (n, oh, ow) map is advanced incrementally by BR pixels per stage.
+    const int px = tid / TPP, tq = tid % TPP;
+    int bkh[CPTB], bkw[CPTB], bci[CPTB];
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-        const int id = tid + i * NTHREADS;
-        const int px = id / BCH, ch = id - px * BCH;
-        bpx[i] = px < BR ? px : -1; bcol[i] = ch;
-        const int k = k0 + ch * V;
+    for (int c = 0; c < CPTB; ++c) {
+        const int k = k0 + (tq * CPTB + c) * V;
         if (k < g.Ktot) {
             const int tap = k / g.Cin;
-            bci[i] = k - tap * g.Cin; bkh[i] = tap / g.KW; bkw[i] = tap - bkh[i] * g.KW;
+            bci[c] = k - tap * g.Cin; bkh[c] = tap / g.KW; bkw[c] = tap - bkh[c] * g.KW;
         } else {
-            bci[i] = -1; bkh[i] = 0; bkw[i] = 0;
+            bci[c] = -1; bkh[c] = 0; bkw[c] = 0;
         }
     }
-    uint4 ra[A_PASSES], rb[B_PASSES];
+    int pn, poh, pow_;     // pixel of the NEXT stage to load
+    {
+        const int m = mbeg + px;
+        pn = m / (g.OH * g.OW);
+        const int rem = m - pn * (g.OH * g.OW);
+        poh = rem / g.OW; pow_ = rem - poh * g.OW;
+    }
+    uint4 ra[CPTA], rb[CPTB];
     auto load_stage = [&](int s) {
-        const int mb = mbeg + s * BR;
+        const int m = mbeg + s * BR + px;
+        const bool mok = m < mend;
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            const int id = tid + i * NTHREADS;
-            const int px = id / ACH, ch = id - px * ACH;
-            const int m = mb + px, co = co0 + ch * V;
+        for (int c = 0; c < CPTA; ++c) {
+            const int ch = tq * CPTA + c;
+            const int co = co0 + ch * V;
             uint4 v = {0u, 0u, 0u, 0u};
-            if (px < BR && m < mend && co < p.ldd) v = *reinterpret_cast<const uint4*>((const T*)p.dy + (size_t)m * p.ldd + co);
-            ra[i] = v;
+            if (mok && ch < ACH && co < p.ldd) v = *reinterpret_cast<const uint4*>((const T*)p.dy + (size_t)m * p.ldd + co);
+            ra[c] = v;
         }
+        const int ih0 = poh * g.stride - g.pad, iw0 = pow_ * g.stride - g.pad;
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) {
+        for (int c = 0; c < CPTB; ++c) {
             uint4 v = {0u, 0u, 0u, 0u};
-            const int m = mb + bpx[i];
-            if (bpx[i] >= 0 && bci[i] >= 0 && m < mend) {
-                const int n = m / (g.OH * g.OW);
-                const int rem = m - n * (g.OH * g.OW);
-                const int oh = rem / g.OW, ow = rem - oh * g.OW;
-                v = gather16<T>(g, n, oh * g.stride - g.pad + bkh[i], ow * g.stride - g.pad + bkw[i], bci[i]);
+            if (mok && bci[c] >= 0) {
+                const T* ptr = gather_ptr<T>(g, pn, ih0 + bkh[c], iw0 + bkw[c], bci[c]);
+                if (ptr) v = *reinterpret_cast<const uint4*>(ptr);
             }
-            rb[i] = v;
+            rb[c] = v;
         }
+        pow_ += BR;
+        while (pow_ >= g.OW) { pow_ -= g.OW; if (++poh == g.OH) { poh = 0; ++pn; } }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            const int id = tid + i * NTHREADS;
-            const int px = id / ACH, ch = id - px * ACH;
-            if (px < BR) *reinterpret_cast<uint4*>(sA + (size_t)(buf * BR + px) * STRA + ch * 16) = ra[i];
+        for (int c = 0; c < CPTA; ++c) {
+            const int ch = tq * CPTA + c;
+            if (ch < ACH) *reinterpret_cast<uint4*>(sA + (size_t)(buf * BR + px) * STRA + ch * 16) = ra[c];
         }
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i)
-            if (bpx[i] >= 0) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BR + bpx[i]) * STRB + bcol[i] * 16) = rb[i];
+        for (int c = 0; c < CPTB; ++c) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BR + px) * STRB + (tq * CPTB + c) * 16) = rb[c];
     };
 
     f32x4 acc[FM][FN];
@@ -448,6 +495,26 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(WGradP p) {
             }
 }
 
+// Tall slab stacks (many pixel splits) are first folded to <= SDE_WGRAD_FOLD_ROWS rows: out[ro] = sum of chunk ro of the rows.
+__global__ void __launch_bounds__(256) slab_fold_kernel(const float* __restrict__ slab, int rows, size_t width4, int chunk, float* __restrict__ out) {
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= width4) return;
+    const int ro = blockIdx.y, r0 = ro * chunk, r1 = min(rows, r0 + chunk);
+    float4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    int r = r0;
+    for (; r + 1 < r1; r += 2) {
+        const float4 u = reinterpret_cast<const float4*>(slab)[(size_t)r * width4 + c];
+        const float4 v = reinterpret_cast<const float4*>(slab)[(size_t)(r + 1) * width4 + c];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (r < r1) {
+        const float4 u = reinterpret_cast<const float4*>(slab)[(size_t)r * width4 + c];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+    reinterpret_cast<float4*>(out)[(size_t)ro * width4 + c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
 // Sum the slabs in fixed order and write the master OIHW fp32 gradient (skipping padded input channels).
 // One workgroup per output channel: the K-major sums go through LDS so that both the slab reads and the OIHW writes are
 // contiguous (the [tap][ci] -> [ci][tap] transpose happens in LDS).
@@ -457,9 +524,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     const int co = blockIdx.x, K = KHW * Cin_pad;
     const size_t total = (size_t)Cout * K;
     for (int k = threadIdx.x; k < K; k += 256) {
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + (size_t)co * K + k];
-        sk[k] = s;
+        const float* src = slab + (size_t)co * K + k;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = 0;
+        for (; sp + 3 < splits; sp += 4) {
+            s0 += src[(size_t)sp * total]; s1 += src[(size_t)(sp + 1) * total];
+            s2 += src[(size_t)(sp + 2) * total]; s3 += src[(size_t)(sp + 3) * total];
+        }
+        for (; sp < splits; ++sp) s0 += src[(size_t)sp * total];
+        sk[k] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     const int n = Cin_real * KHW;
@@ -504,6 +577,31 @@ __global__ void __launch_bounds__(256) pack_w_dgrad_kernel(const float* __restri
     }
 }
 
+// All layers' operands in ONE launch: items[] (device) describe each pack job; `end` is the exclusive prefix sum of output
+// elements, so a grid-stride index finds its job by binary search.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_batched_kernel(const sde_pack_item* __restrict__ items, int n, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (items[mid].end > i) hi = mid; else lo = mid + 1;
+        }
+        const sde_pack_item it = items[lo];
+        const long j = i - (lo ? items[lo - 1].end : 0);
+        const int khw = it.KH * it.KW;
+        float v = 0.f;
+        if (!it.for_dgrad) {          // [Cout_pad][KH][KW][Cin_pad]
+            const int ci = (int)(j % it.Cin_pad), tap = (int)((j / it.Cin_pad) % khw), co = (int)(j / ((long)it.Cin_pad * khw));
+            if (ci < it.Cin && co < it.Cout) v = it.src[((size_t)co * it.Cin + ci) * khw + tap];
+        } else {                      // [Cin_pad][KH][KW][Cout_pad], taps flipped
+            const int co = (int)(j % it.Cout_pad), tapf = (int)((j / it.Cout_pad) % khw), ci = (int)(j / ((long)it.Cout_pad * khw));
+            if (ci < it.Cin && co < it.Cout) v = it.src[((size_t)co * it.Cin + ci) * khw + (khw - 1 - tapf)];
+        }
+        ((T*)it.dst)[j] = from_f32<T>(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------------------------
@@ -517,7 +615,7 @@ int launch_igemm(const IGemmP& p, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    dim3 grid(sde_cdiv(p.g.M, BM), sde_cdiv(p.ldy, BN));
+    dim3 grid(sde_cdiv(p.g.M, BM) * sde_cdiv(p.ldy, BN));
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), grid, dim3(NTHREADS), lds, s, p);
     return 0;
 }
@@ -552,7 +650,7 @@ int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMG, BNG, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    dim3 grid(sde_cdiv(p.Cout, BMG), sde_cdiv(p.g.Ktot, BNG), splits);
+    dim3 grid(sde_cdiv(p.Cout, BMG) * sde_cdiv(p.g.Ktot, BNG) * splits);
     hipLaunchKernelGGL((wgrad_kernel<T, BMG, BNG, WM, WN>), grid, dim3(NTHREADS), lds, s, p);
     return 0;
 }
@@ -660,7 +758,18 @@ int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         red_attr = true;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), lds_red, s, slab, splits, Cout, d->KH * d->KW, p.g.Cin, Cin_real, dw, accumulate);
+    const float* red_src = slab;
+    int red_rows = splits;
+    if (splits > SDE_WGRAD_FOLD_ROWS) {     // fold into the SDE_WGRAD_FOLD_ROWS scratch rows behind the slab stack
+        const size_t width4 = (size_t)Cout * p.g.Ktot / 4;      // Ktot is a multiple of 4 elements
+        const int chunk = sde_cdiv(splits, SDE_WGRAD_FOLD_ROWS);
+        red_rows = sde_cdiv(splits, chunk);
+        float* scratch = slab + (size_t)splits * Cout * p.g.Ktot;
+        hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((width4 + 255) / 256), red_rows), dim3(256), 0, s, slab, splits, width4, chunk, scratch);
+        SDE_CHECK_LAUNCH("sde_conv_wgrad/fold");
+        red_src = scratch;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), lds_red, s, red_src, red_rows, Cout, d->KH * d->KW, p.g.Cin, Cin_real, dw, accumulate);
     SDE_CHECK_LAUNCH("sde_conv_wgrad/reduce");
     return SDE_OK;
 }
@@ -681,6 +790,17 @@ int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int
         else hipLaunchKernelGGL(pack_w_fwd_kernel<float>, dim3(nb), dim3(256), 0, s, w, (float*)out, Cout, Cin, KH, KW, Cin_pad, Cout_pad);
     }
     SDE_CHECK_LAUNCH("sde_pack_weight");
+    return SDE_OK;
+}
+
+int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total, int dtype, sde_stream_t stream) {
+    SDE_CHECK_ARG(items_dev && n > 0 && total > 0, "sde_pack_weights_batched: bad argument");
+    SDE_CHECK_ARG(dtype == SDE_F32 || dtype == SDE_BF16, "sde_pack_weights_batched: bad dtype");
+    long nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    if (dtype == SDE_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, items_dev, n, total);
+    else hipLaunchKernelGGL(pack_batched_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, items_dev, n, total);
+    SDE_CHECK_LAUNCH("sde_pack_weights_batched");
     return SDE_OK;
 }
 

@@ -145,55 +145,76 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
-// Channel reduction pass of BN backward: partial[blk][C][2] = (sum dz, sum dz*xhat), dz = dout * (out > 0 if relu)
-constexpr int RED_ROWS = 8;   // a 256-thread block = (C/V chunk columns) x rows; here handled generically below
+// Combine per-thread column accumulators of a 256-thread block whose threads tid, tid+cch, tid+2cch, ... share a 16-byte
+// channel group (cch = groups per row, a divisor of 256).  sh: [256][NV] floats.  Thread t < cch returns the block sums of its
+// group in a[]; no float atomics (deterministic, and LDS float atomics are slow).
+template <int NV>
+__device__ __forceinline__ void block_group_reduce(float (&a)[NV], int cch, float* sh) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) sh[t * NV + e] = a[e];
+    __syncthreads();
+    if (t < cch) {
+        for (int r = t + cch; r < 256; r += cch)
+#pragma unroll
+            for (int e = 0; e < NV; ++e) a[e] += sh[r * NV + e];
+    }
+}
+
+// Channel reduction pass of BN backward: partial[blk][C][2] = (sum dz, sum dz*xhat), dz = dout * (out > 0 if relu).
+// Grid-stride over (row, 16-byte group) items; gridDim*256 is a multiple of the groups per row, so a thread's group is fixed.
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y,
                                                             const float* __restrict__ bnp, int relu, long M, int C, long rows_per_block,
                                                             float* __restrict__ part) {
     constexpr int V = VecOf<T>::V;
-    extern __shared__ float sh[];   // [2][C] accumulators shared by the block
+    extern __shared__ float sh[];   // fast path: [256][2V]; fallback: [2][C]
     const int cch = C / V;
+    if (cch <= 256 && 256 % cch == 0) {
+        const int col = threadIdx.x % cch, c0 = col * V;
+        float mean[V], rstd[V], acc[2 * V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { mean[e] = bnp[c0 + e]; rstd[e] = bnp[C + c0 + e]; acc[e] = 0.f; acc[V + e] = 0.f; }
+        const long total = M * cch;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            float d[V], o[V], yv[V];
+            load_vec<T>(dout + i * V, d);
+            load_vec<T>(y + i * V, yv);
+            if (relu) {
+                load_vec<T>(out + i * V, o);
+#pragma unroll
+                for (int e = 0; e < V; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) { acc[e] += d[e]; acc[V + e] += d[e] * ((yv[e] - mean[e]) * rstd[e]); }
+        }
+        block_group_reduce<2 * V>(acc, cch, sh);
+        if (threadIdx.x < cch) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                part[((size_t)blockIdx.x * C + c0 + e) * 2] = acc[e];
+                part[((size_t)blockIdx.x * C + c0 + e) * 2 + 1] = acc[V + e];
+            }
+        }
+        return;
+    }
+    // generic fallback (more 16-byte groups per row than threads): shared float atomics
     for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
     __syncthreads();
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    // thread -> fixed chunk column when cch divides 256 or vice versa; general case handled by striding over (row, chunk)
     const long total = (r1 - r0) * cch;
-    if (cch <= 256 && 256 % cch == 0) {
-        const int col = threadIdx.x % cch, c0 = col * V;
-        const int rstep = 256 / cch;
-        float a1[V], a2[V];
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int col = (int)(i % cch), c0 = col * V;
+        const long off = (r0 * cch + i) * V;
+        float d[V], o[V], yv[V];
+        load_vec<T>(dout + off, d);
+        if (relu) load_vec<T>(out + off, o);
+        load_vec<T>(y + off, yv);
 #pragma unroll
-        for (int e = 0; e < V; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
-        for (long r = r0 + threadIdx.x / cch; r < r1; r += rstep) {
-            const long off = (r * cch + col) * V;
-            float d[V], o[V], yv[V];
-            load_vec<T>(dout + off, d);
-            if (relu) load_vec<T>(out + off, o);
-            load_vec<T>(y + off, yv);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const float dz = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
-                const float xh = (yv[e] - bnp[c0 + e]) * bnp[C + c0 + e];
-                a1[e] += dz; a2[e] += dz * xh;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < V; ++e) { atomicAdd(&sh[c0 + e], a1[e]); atomicAdd(&sh[C + c0 + e], a2[e]); }
-    } else {
-        for (long i = threadIdx.x; i < total; i += 256) {
-            const int col = (int)(i % cch), c0 = col * V;
-            const long off = (r0 * cch + i) * V;
-            float d[V], o[V], yv[V];
-            load_vec<T>(dout + off, d);
-            if (relu) load_vec<T>(out + off, o);
-            load_vec<T>(y + off, yv);
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const float dz = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
-                const float xh = (yv[e] - bnp[c0 + e]) * bnp[C + c0 + e];
-                atomicAdd(&sh[c0 + e], dz); atomicAdd(&sh[C + c0 + e], dz * xh);
-            }
+        for (int e = 0; e < V; ++e) {
+            const float dz = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
+            const float xh = (yv[e] - bnp[c0 + e]) * bnp[C + c0 + e];
+            atomicAdd(&sh[c0 + e], dz); atomicAdd(&sh[C + c0 + e], dz * xh);
         }
     }
     __syncthreads();
@@ -325,8 +346,37 @@ template <typename T>
 __global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__ dout, const T* __restrict__ out, int act, long M, int C,
                                                            long rows_per_block, T* __restrict__ dz, float* __restrict__ part) {
     constexpr int V = VecOf<T>::V;
-    extern __shared__ float sh[];   // [C]
+    extern __shared__ float sh[];   // fast path: [256][V]; fallback: [C]
     const int cch = C / V;
+    if (cch <= 256 && 256 % cch == 0) {
+        const int col = threadIdx.x % cch, c0 = col * V;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        const long total = M * cch;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            float d[V], o[V];
+            load_vec<T>(dout + i * V, d);
+            if (act != SDE_ACT_NONE) {
+                load_vec<T>(out + i * V, o);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    if (act == SDE_ACT_ELU) d[e] = o[e] > 0.f ? d[e] : d[e] * (o[e] + 1.0f);     // ELU'(x) = exp(x) = out + 1 for x <= 0
+                    else d[e] = o[e] > 0.f ? d[e] : 0.f;
+                }
+            }
+            if (dz) store_vec<T>(dz + i * V, d);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += d[e];
+        }
+        if (part) {
+            block_group_reduce<V>(acc, cch, sh);
+            if (threadIdx.x < cch)
+#pragma unroll
+                for (int e = 0; e < V; ++e) part[(size_t)blockIdx.x * C + c0 + e] = acc[e];
+        }
+        return;
+    }
     if (part) {
         for (int i = threadIdx.x; i < C; i += 256) sh[i] = 0.f;
         __syncthreads();
@@ -342,7 +392,7 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__
             load_vec<T>(out + off, o);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                if (act == SDE_ACT_ELU) d[e] = o[e] > 0.f ? d[e] : d[e] * (o[e] + 1.0f);     // ELU'(x) = exp(x) = out + 1 for x <= 0
+                if (act == SDE_ACT_ELU) d[e] = o[e] > 0.f ? d[e] : d[e] * (o[e] + 1.0f);
                 else if (act == SDE_ACT_RELU) d[e] = o[e] > 0.f ? d[e] : 0.f;
             }
         }
@@ -740,7 +790,7 @@ int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bn
     hipStream_t s = (hipStream_t)stream;
     const int nblk = sde_reduce_num_blocks(M);
     const long rpb = (M + nblk - 1) / nblk;
-    const size_t lds = 2 * (size_t)C * sizeof(float);
+    const size_t lds = (2 * (size_t)C > 256 * 16 ? 2 * (size_t)C : 256 * 16) * sizeof(float);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)y, bnp, relu, M, C, rpb, part),
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part));
@@ -791,7 +841,7 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
     const int nblk = sde_reduce_num_blocks(M);
     const long rpb = (M + nblk - 1) / nblk;
     float* p = dbias ? part : nullptr;
-    const size_t lds = (size_t)C * sizeof(float);
+    const size_t lds = ((size_t)C > 256 * 8 ? (size_t)C : 256 * 8) * sizeof(float);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(act_bwd_bias_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, act, M, C, rpb, (float*)dz, p),
                hipLaunchKernelGGL(act_bwd_bias_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, act, M, C, rpb, (bf16_t*)dz, p));

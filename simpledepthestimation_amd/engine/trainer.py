@@ -78,6 +78,8 @@ class HipTrainer:
         self._graph = None
         self._static_batch = None
         self._static_out = None
+        self._packer = None            # built lazily after the first eager step (needs the operand shapes seen in forward)
+        self.batch_pack = adam_fn is None
 
     # ------------------------------------------------------------------------------------------------------------
     def set_lr(self, lrs):
@@ -88,10 +90,17 @@ class HipTrainer:
 
     def _fwd_bwd(self, batch):
         self.gflat.zero_()
+        if self._packer is not None:
+            self._packer.run()                      # every conv operand of the step in one launch
         out = self.model(batch)
         loss_dict = {k: v for k, v in out.items() if "loss" in k}
         losses = sum(loss_dict.values())
         losses.backward()
+        if self._packer is None and self.batch_pack:
+            try:
+                self._packer = HN.WeightPacker(self.model)
+            except Exception:
+                self.batch_pack = False             # model without HIP convolutions
         return loss_dict
 
     def _allreduce(self):

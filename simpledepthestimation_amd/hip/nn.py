@@ -24,6 +24,7 @@ class ConvDesc(Structure):
 _P, _I, _F, _LG = c_void_p, c_int, c_float, c_long
 L.register_protos({
     "sde_pack_weight": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
+    "sde_pack_weights_batched": ([_P, _I, _LG, _I, _P], c_int),
     "sde_conv_fwd": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P], c_int),
     "sde_conv_fwd_tiles_m": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_fwd_variant": ([POINTER(ConvDesc), _I], c_int),
@@ -137,7 +138,7 @@ def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device, kin
 # ---------------------------------------------------------------------------------------------------------------
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, stride, pad, reflect, act, upcat, want_stats):
+    def forward(ctx, x0, x1, weight, bias, stride, pad, reflect, act, upcat, want_stats, owner=None):
         if not x0.is_contiguous() or (x1 is not None and not x1.is_contiguous()):
             raise L.SdeHipError("conv2d: NHWC inputs must be contiguous")
         dt = x0.dtype
@@ -154,7 +155,13 @@ class _Conv2d(torch.autograd.Function):
         OW = (IW + 2 * pad - KW) // stride + 1
         ldy = pad_to(Cout, V)
         d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
-        wp = pack_weight(weight, dt, C0 + C1, ldy)
+        pre = getattr(owner, "_packed", None) if owner is not None else None
+        if pre is not None and pre[0].dtype == dt and pre[0].shape == (ldy, KH, KW, C0 + C1):
+            wp, ctx.wd_pre = pre                                   # operands packed once per step by WeightPacker
+        else:
+            wp, ctx.wd_pre = pack_weight(weight, dt, C0 + C1, ldy), None
+            if owner is not None:
+                owner._pack_shapes = (dt, C0 + C1, ldy)            # lets WeightPacker build its job table after a first step
         b32 = _f32(bias) if bias is not None else None
         flops = 2.0 * B * OH * OW * Cout * KH * KW * Cin          # algorithmic (real channels)
         y, stats = conv_raw(d, dt, wp, b32, act, Cout, ldy, want_stats, x0.device, "igemm_fwd", flops)
@@ -201,7 +208,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
             splits = lib.sde_conv_wgrad_splits(ctypes.byref(d), Cout)
-            slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
+            slab = torch.empty(splits + 16, Cout, KH * KW * (C0 + C1), device=dev)       # + SDE_WGRAD_FOLD_ROWS scratch rows
             wslot = _grad_slot(ctx.params[0])
             dw = wslot if wslot is not None else torch.empty_like(weight)
             meta = None
@@ -217,7 +224,7 @@ class _Conv2d(torch.autograd.Function):
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             Cv = C0 + C1
-            wd = pack_weight(weight, dt, Cv, ldy, for_dgrad=True)          # [Cv][KH][KW][ldy], taps flipped
+            wd = ctx.wd_pre if ctx.wd_pre is not None else pack_weight(weight, dt, Cv, ldy, for_dgrad=True)   # [Cv][KH][KW][ldy], taps flipped
             if reflect:
                 dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1, False, OH, OW, IH + 2, IW + 2)
                 dxp, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
@@ -235,16 +242,60 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     raise L.SdeHipError(f"stride {stride} not supported")
                 dx0, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
-        return dx0, dx1, dw, dbias, None, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, skip=None, upsample=False, bn_stats=False):
+class PackItem(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("Cout", c_int32), ("Cin", c_int32), ("KH", c_int32), ("KW", c_int32), ("Cin_pad", c_int32),
+                ("Cout_pad", c_int32), ("for_dgrad", c_int32), ("reserved", c_int32), ("end", ctypes.c_int64)]
+
+
+class WeightPacker:
+    """Packs the forward and data-gradient operands of every convolution of a model in ONE kernel launch per step.
+
+    Build it after one forward pass (each HipConv2d then knows the padded shapes its operands need); call run() whenever the master
+    weights changed (HipTrainer does, at the start of every step, inside the captured graph)."""
+
+    def __init__(self, model):
+        import numpy as np
+        convs = [m for m in model.modules() if getattr(m, "_pack_shapes", None) is not None]
+        if not convs:
+            raise L.SdeHipError("WeightPacker: run one forward pass first")
+        self.dtype = convs[0]._pack_shapes[0]
+        items, end = [], 0
+        self._keep = []
+        for m in convs:
+            dt, cin_pad, ldy = m._pack_shapes
+            if dt != self.dtype:
+                raise L.SdeHipError("WeightPacker: mixed compute dtypes")
+            w = m.weight
+            Cout, Cin, KH, KW = w.shape
+            wp = torch.empty(ldy, KH, KW, cin_pad, device=w.device, dtype=dt)
+            wd = torch.empty(cin_pad, KH, KW, ldy, device=w.device, dtype=dt)
+            m._packed = (wp, wd)
+            for dst, for_dgrad in ((wp, 0), (wd, 1)):
+                end += dst.numel()
+                items.append((w.data_ptr(), dst.data_ptr(), Cout, Cin, KH, KW, cin_pad, ldy, for_dgrad, 0, end))
+            self._keep.append((w, wp, wd))
+        arr = (PackItem * len(items))(*[PackItem(*it) for it in items])
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        self.items = torch.from_numpy(raw).to(convs[0].weight.device)
+        self.n, self.total = len(items), end
+        self._ptrs = [w.data_ptr() for w, _, _ in self._keep]
+
+    def run(self):
+        if any(w.data_ptr() != p for (w, _, _), p in zip(self._keep, self._ptrs)):
+            raise L.SdeHipError("WeightPacker: a weight tensor moved (e.g. flattened after the packer was built); rebuild the packer")
+        L.check(L.lib().sde_pack_weights_batched(L.ptr(self.items), self.n, self.total, dtype_code(self.dtype), L.stream()), "sde_pack_weights_batched")
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, skip=None, upsample=False, bn_stats=False, owner=None):
     """y = act(conv(x) + bias) on NHWC tensors.
 
     upsample=True: the input is cat(nearest_x2(x), skip) (skip may be None) -- depth_decoder.py:L102-105 -- gathered on the fly.
     bn_stats=True additionally returns the per-tile (sum, sum^2) slab BatchNorm needs.
     """
-    return _Conv2d.apply(x, skip, weight, bias, int(stride), int(pad), bool(reflect), int(act), bool(upsample), bool(bn_stats))
+    return _Conv2d.apply(x, skip, weight, bias, int(stride), int(pad), bool(reflect), int(act), bool(upsample), bool(bn_stats), owner)
 
 
 # ---------------------------------------------------------------------------------------------------------------

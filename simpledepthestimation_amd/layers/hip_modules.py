@@ -20,6 +20,8 @@ class HipConv2d(nn.Module):
         self.stride, self.padding, self.reflect = int(stride), int(padding), bool(reflect)
         self.weight = nn.Parameter(torch.empty(self.out_channels, self.in_channels, self.kernel_size, self.kernel_size))
         self.bias = nn.Parameter(torch.empty(self.out_channels)) if bias else None
+        self._packed = None        # (forward operand, dgrad operand) maintained by hip.nn.WeightPacker, else packed per call
+        self._pack_shapes = None
         self.reset_parameters()
 
     def reset_parameters(self):   # torch.nn.Conv2d default initialisation
@@ -29,7 +31,7 @@ class HipConv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x, skip=None, upsample=False, act=HN.ACT_NONE, bn_stats=False):
-        return HN.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.reflect, act, skip, upsample, bn_stats)
+        return HN.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.reflect, act, skip, upsample, bn_stats, owner=self)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, reflect={self.reflect}"
