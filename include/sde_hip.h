@@ -175,9 +175,9 @@ int sde_bn_eval_params(const float* gamma, const float* beta, const float* runni
                        sde_stream_t stream);
 /* out = [relu](y*scale + shift [+ residual]) */
 int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu, long M, int C, int dtype, void* out, sde_stream_t stream);
-/* BatchNorm(+ReLU, +residual) backward.  part: [sde_reduce_num_blocks(M) + SDE_REDUCE_ROWS][C][2] workspace, coef: [2][C] workspace.
+/* BatchNorm(+ReLU, +residual) backward.  part: [sde_reduce_num_blocks(M, C) + SDE_REDUCE_ROWS][C][2] workspace, coef: [2][C] workspace.
  * dy [M,C]; dres (optional) [M,C] = gradient of the residual input; dgamma/dbeta [C] (+)=. */
-int sde_reduce_num_blocks(long M);
+int sde_reduce_num_blocks(long M, int C);
 int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, const float* gamma, int relu, long M, int C, int dtype, float* part,
                float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dy, void* dres, sde_stream_t stream);
 
@@ -186,7 +186,7 @@ int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* 
 int sde_maxpool_bwd(const void* dout, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream);
 
 /* dz = dout * act'(out) (nn.ELU / nn.ReLU backward) fused with the bias gradient dbias[c] (+)= sum_rows dz[:, c], c < Cbias.
- * dz and/or dbias may be NULL; part: [sde_reduce_num_blocks(M) + SDE_REDUCE_ROWS][C] workspace (needed when dbias != NULL). */
+ * dz and/or dbias may be NULL; part: [sde_reduce_num_blocks(M, C) + SDE_REDUCE_ROWS][C] workspace (needed when dbias != NULL). */
 int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias, int accumulate,
                      sde_stream_t stream);
 

@@ -19,10 +19,14 @@
 //     partials for training-mode BatchNorm (deterministic: no atomics).
 //   * weight gradient: reduction over pixels with both operands read transposed out of LDS (ds_read_b64_tr_b16), split
 //     over pixel ranges into fp32 slabs that a second kernel sums in fixed order (bit-reproducible gradients).
+#include <type_traits>
+
 #include "common.h"
 #include "sde_hip.h"
 
 namespace {
+
+template <int I> using IC = std::integral_constant<int, I>;
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -132,8 +136,56 @@ __device__ __forceinline__ const T* gather_ptr(const Gather& g, int n, int ih, i
     return (const T*)g.x0 + ((size_t)((n * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1))) * g.C0 + ci;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(NTHREADS) igemm_kernel(IGemmP p) {
+// ---- branch-free gather: byte offsets for hardware-bounds-checked buffer loads (an out-of-range offset reads zeros), so
+// padding, inserted zeros and ragged tiles cost no control flow and the compiler can keep several stages of loads in flight.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr unsigned kOOB = 0x80000000u;      // every tensor is < 2 GiB, so this offset is always out of range
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// Source kinds.  bf16 kernels are specialised on the kind (straight-line loop bodies: with the kind decided at run time the
+// loop breaks into ~70 basic blocks per 32 MFMAs and nothing overlaps); SRC_RUNTIME keeps one generic fp32 instantiation.
+constexpr int SRC_RUNTIME = -1, SRC_PLAIN_ZERO = 0, SRC_PLAIN_REFLECT = 1, SRC_UPCAT_REFLECT = 2, SRC_ZEROINS_ZERO = 3, SRC_1X1 = 4;
+
+template <int SRC> __device__ __forceinline__ int src_mode(const Gather& g) {
+    if (SRC == SRC_RUNTIME) return g.mode;
+    return SRC == SRC_UPCAT_REFLECT ? SDE_SRC_UPCAT : (SRC == SRC_ZEROINS_ZERO ? SDE_SRC_ZEROINS : SDE_SRC_PLAIN);
+}
+template <int SRC> __device__ __forceinline__ bool src_reflect(const Gather& g) {
+    if (SRC == SRC_RUNTIME) return g.reflect != 0;
+    return SRC == SRC_PLAIN_REFLECT || SRC == SRC_UPCAT_REFLECT;
+}
+
+// offsets (bytes) of the 16-byte group (n, ih, iw, ci) in source 0 / source 1; kOOB where it is padding / not that source
+template <typename T, int SRC>
+__device__ __forceinline__ void gather_off(const Gather& g, bool ok, int n, int ih, int iw, int ci, unsigned& o0, unsigned& o1) {
+    const int mode = src_mode<SRC>(g);
+    if (src_reflect<SRC>(g)) { ih = reflect1(ih, g.IH); iw = reflect1(iw, g.IW); }
+    else ok = ok & ((unsigned)ih < (unsigned)g.IH) & ((unsigned)iw < (unsigned)g.IW);
+    o1 = kOOB;
+    if (mode == SDE_SRC_PLAIN) {
+        const unsigned o = (unsigned)(((n * g.H0 + ih) * g.W0 + iw) * g.C0 + ci) * (unsigned)sizeof(T);
+        o0 = ok ? o : kOOB;
+    } else if (mode == SDE_SRC_UPCAT) {
+        const bool first = ci < g.C0;
+        const unsigned oa = (unsigned)(((n * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1)) * g.C0 + ci) * (unsigned)sizeof(T);
+        const unsigned ob = (unsigned)(((n * g.IH + ih) * g.IW + iw) * g.C1 + (ci - g.C0)) * (unsigned)sizeof(T);
+        o0 = (ok & first) ? oa : kOOB;
+        o1 = (ok & !first) ? ob : kOOB;
+    } else {
+        ok = ok & !((ih | iw) & 1);
+        const unsigned o = (unsigned)(((n * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1)) * g.C0 + ci) * (unsigned)sizeof(T);
+        o0 = ok ? o : kOOB;
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int SRC, bool ONE_TAP>
+__global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
     constexpr int V = VecOf<T>::V;
     constexpr int BK = KSTAGE_BYTES / (int)sizeof(T);
     constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile
@@ -178,45 +230,77 @@ __global__ void __launch_bounds__(NTHREADS) igemm_kernel(IGemmP p) {
     // ---- B side (weights, plain 2-D): rows r0 + 32 i, chunk column cc
     const int cc = tid & 7, r0 = tid >> 3;
     const int nk = (g.Ktot + BK - 1) / BK;
-    uint4 ra[CPT], rb[B_PASSES];
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(g.x0, (long)g.Bn * g.H0 * g.W0 * g.C0 * (long)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1 ? g.x1 : g.x0, g.x1 ? (long)g.Bn * g.IH * g.IW * g.C1 * (long)sizeof(T) : 0);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (long)p.Cout * g.Ktot * (long)sizeof(T));
+    // ONE_TAP: a thread's CPT chunks are 16-byte groups of one filter tap (channel counts multiples of CPT*V: every layer but the
+    // image / 16-channel ones), so one offset per stage serves all of them.  SRC_1X1: no taps at all, offset = row base + k.
+    const int mode = src_mode<SRC>(g);
+    unsigned rowoff = kOOB;        // SRC_1X1: byte offset of this thread's input pixel
+    if (SRC == SRC_1X1 && an >= 0) rowoff = (unsigned)(((an * g.H0 + aih) * g.W0 + aiw) * g.C0) * (unsigned)sizeof(T);
 
-    auto load_stage = [&](int s) {
-        int ci = aci, kh = akh, kw = akw;
-        const T* ptr = nullptr;
+    // Three register stages in flight over two LDS buffers: the loop is bound by load latency, not by MFMA issue, so stage s+3
+    // is requested while stage s is multiplied and stage s+1 is written to LDS (the compiler's counted vmcnt keeps s+2, s+3 flying).
+    uint4 ra[3][CPT], rb[3][B_PASSES];
+
+    auto load_stage = [&](int s, auto SET) {
+        constexpr int st = decltype(SET)::value;
+        if (SRC == SRC_1X1) {
+            const int k = s * BK + ac0 * V;
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (an >= 0 && kh < g.KH) {
-                if (c == 0 || ci == 0 || (g.mode == SDE_SRC_UPCAT && ci == g.C0)) ptr = gather_ptr<T>(g, an, aih + kh, aiw + kw, ci);
-                else if (ptr) ptr += V;
-                if (ptr) v = *reinterpret_cast<const uint4*>(ptr);
+            for (int c = 0; c < CPT; ++c)
+                ra[st][c] = buf_load16(rs0, (an >= 0 && k + c * V < g.Ktot) ? rowoff + (unsigned)(k + c * V) * (unsigned)sizeof(T) : kOOB);
+        } else if (ONE_TAP) {
+            unsigned o0, o1;
+            gather_off<T, SRC>(g, an >= 0 && akh < g.KH, an, aih + akh, aiw + akw, aci, o0, o1);
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                uint4 v = buf_load16(rs0, o0 + 16u * c);       // kOOB + 16c stays out of range
+                if (mode == SDE_SRC_UPCAT) {
+                    const uint4 u = buf_load16(rs1, o1 + 16u * c);
+                    v.x |= u.x; v.y |= u.y; v.z |= u.z; v.w |= u.w;
+                }
+                ra[st][c] = v;
             }
-            ra[c] = v;
-            ci += V;
-            if (ci == g.Cin) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+        } else {
+            int ci = aci, kh = akh, kw = akw;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                unsigned o0, o1;
+                gather_off<T, SRC>(g, an >= 0 && kh < g.KH, an, aih + kh, aiw + kw, ci, o0, o1);
+                uint4 v = buf_load16(rs0, o0);
+                if (mode == SDE_SRC_UPCAT) {
+                    const uint4 u = buf_load16(rs1, o1);
+                    v.x |= u.x; v.y |= u.y; v.z |= u.z; v.w |= u.w;
+                }
+                ra[st][c] = v;
+                ci += V;
+                if (ci == g.Cin) { ci = 0; if (++kw == g.KW) { kw = 0; ++kh; } }
+            }
         }
-        // advance the thread's base position by one stage (BK elements)
-        aci += BK;
-        while (aci >= g.Cin) { aci -= g.Cin; if (++akw == g.KW) { akw = 0; ++akh; } }
+        if (SRC != SRC_1X1) {       // advance the thread's base (tap, channel) position by one stage (BK elements)
+            aci += BK;
+            while (aci >= g.Cin) { aci -= g.Cin; if (++akw == g.KW) { akw = 0; ++akh; } }
+        }
         const int k = s * BK + cc * V;
         const bool kok = k < g.Ktot;
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int row = r0 + i * B_ROWS_PER_PASS;
             const int n = n0 + row;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (kok && row < BN && n < p.Cout) v = *reinterpret_cast<const uint4*>((const T*)p.w + (size_t)n * g.Ktot + k);
-            rb[i] = v;
+            const unsigned ow = (kok && row < BN && n < p.Cout) ? (unsigned)(n * g.Ktot + k) * (unsigned)sizeof(T) : kOOB;
+            rb[st][i] = buf_load16(rsw, ow);
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, auto SET) {
+        constexpr int st = decltype(SET)::value;
 #pragma unroll
         for (int c = 0; c < CPT; ++c)
-            *reinterpret_cast<uint4*>(sA + (size_t)(buf * BM + arow) * KSTAGE_BYTES + (((ac0 + c) ^ (arow & 7)) << 4)) = ra[c];
+            *reinterpret_cast<uint4*>(sA + (size_t)(buf * BM + arow) * KSTAGE_BYTES + (((ac0 + c) ^ (arow & 7)) << 4)) = ra[st][c];
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int row = r0 + i * B_ROWS_PER_PASS;
-            if (row < BN) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = rb[i];
+            if (row < BN) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = rb[st][i];
         }
     };
 
@@ -226,13 +310,8 @@ __global__ void __launch_bounds__(NTHREADS) igemm_kernel(IGemmP p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
-    for (int s = 0; s < nk; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nk) load_stage(s + 1);
+    auto compute_stage = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             uint4 a[FM], b[FN];
@@ -252,8 +331,25 @@ __global__ void __launch_bounds__(NTHREADS) igemm_kernel(IGemmP p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = mma64<T>(a[i], b[j], acc[i][j]);
         }
-        if (s + 1 < nk) store_stage(buf ^ 1);
+    };
+    // one pipeline step: request stage st+3 into the register set that stage st just vacated, multiply stage st out of LDS,
+    // then publish stage st+1 (requested two steps ago) into the other LDS buffer.
+    auto step = [&](int st, auto CUR, auto NXT) {
+        if (st >= nk) return;
+        if (st + 3 < nk) load_stage(st + 3, CUR);
+        compute_stage(st & 1);
+        if (st + 1 < nk) store_stage((st + 1) & 1, NXT);
         __syncthreads();
+    };
+    load_stage(0, IC<0>{});
+    if (nk > 1) load_stage(1, IC<1>{});
+    if (nk > 2) load_stage(2, IC<2>{});
+    store_stage(0, IC<0>{});
+    __syncthreads();
+    for (int s = 0; s < nk; s += 3) {
+        step(s, IC<0>{}, IC<1>{});
+        step(s + 1, IC<1>{}, IC<2>{});
+        step(s + 2, IC<2>{}, IC<0>{});
     }
 
     // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> bias/act -> coalesced NHWC stores (+ BN partials) ----
@@ -333,13 +429,16 @@ template <> struct TrRead<bf16_t> {
     // 32 pixels per sub-block; lane group g needs pixels 8g..8g+7 of column (lane&15): two ds_read_b64_tr_b16
     static __device__ __forceinline__ uint4 rd(const unsigned char* tile, int stride, int p0, int col0, int lane) {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-        const unsigned char* a0 = tile + (size_t)(p0 + 8 * g + q) * stride + (size_t)(col0 + 4 * pp) * 2;
+        // rows whose bit 3 is set are stored with their two 128-byte halves swapped (see wgrad_kernel): with the 288-byte row
+        // stride the eight 4-lane groups of a 32-lane half then read eight disjoint 8-bank groups (conflict-free tr-reads)
+        const int row = p0 + 8 * g + q;
+        const unsigned char* a0 = tile + (size_t)row * stride + (size_t)((((col0 + 4 * pp) * 2)) ^ ((row & 8) << 4));
 #if defined(SDE_WGRAD_SAFE_READ)
         // reference path: element-wise transposed gather (slow, used to validate the tr-read mapping)
         const int col = col0 + i;
         s16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const short*>(tile + (size_t)(p0 + 8 * g + j) * stride + (size_t)col * 2);
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const short*>(tile + (size_t)(p0 + 8 * g + j) * stride + (size_t)((col * 2) ^ (((p0 + 8 * g + j) & 8) << 4)));
         (void)a0;
         return __builtin_bit_cast(uint4, v);
 #else
@@ -365,16 +464,20 @@ template <> struct TrRead<float> {
     }
 };
 
-template <typename T, int BMG, int BNG, int WM, int WN>
-__global__ void __launch_bounds__(NTHREADS) wgrad_kernel(WGradP p) {
+template <typename T, int BMG, int BNG, int WM, int WN, int SRC, bool ONE_TAP>
+__global__ void __launch_bounds__(NTHREADS, 2) wgrad_kernel(WGradP p) {
     constexpr int V = VecOf<T>::V;
     constexpr int BR = WGTraits<T>::BR;
     constexpr int SUBP = 64 / (int)sizeof(T);          // pixels per MFMA sub-block (32 bf16 / 16 f32)
     constexpr int NSUB = BR / SUBP;
     constexpr int WTM = BMG / WM, WTN = BNG / WN;
     constexpr int FM = WTM / 16, FN = WTN / 16;
-    constexpr int STRA = BMG * (int)sizeof(T) + 16;    // padded LDS row strides (bytes)
-    constexpr int STRB = BNG * (int)sizeof(T) + 16;
+    // LDS row strides (bytes).  bf16: 288 B = 72 banks (== 8 mod 64) for every tile width, plus the half-swap XOR of rows with
+    // bit 3 set -> transposed reads are bank-conflict free; fp32 (parity mode): plain padded rows.
+    constexpr int STRA = sizeof(T) == 2 ? 288 : BMG * (int)sizeof(T) + 16;
+    constexpr int STRB = sizeof(T) == 2 ? 288 : BNG * (int)sizeof(T) + 16;
+    constexpr int SWZ = sizeof(T) == 2 ? 1 : 0;
+    static_assert(sizeof(T) != 2 || (BMG <= 128 && BNG <= 128), "bf16 rows must fit the 288-byte stride with the half swap");
     constexpr int ACH = BMG / V, BCH = BNG / V;        // 16-byte chunks per pixel row
     constexpr int TPP = NTHREADS / BR;                 // threads per pixel row (4 bf16 / 8 f32)
     constexpr int CPTB = BCH / TPP;                    // B chunks per thread (4)
@@ -415,39 +518,66 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(WGradP p) {
         const int rem = m - pn * (g.OH * g.OW);
         poh = rem / g.OW; pow_ = rem - poh * g.OW;
     }
-    uint4 ra[CPTA], rb[CPTB];
-    auto load_stage = [&](int s) {
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(g.x0, (long)g.Bn * g.H0 * g.W0 * g.C0 * (long)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1 ? g.x1 : g.x0, g.x1 ? (long)g.Bn * g.IH * g.IW * g.C1 * (long)sizeof(T) : 0);
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(p.dy, (long)g.M * p.ldd * (long)sizeof(T));
+    const int mode = src_mode<SRC>(g);
+    uint4 ra[3][CPTA], rb[3][CPTB];     // three register stages in flight (see igemm_kernel)
+    auto load_stage = [&](int s, auto SET) {
+        constexpr int st = decltype(SET)::value;
         const int m = mbeg + s * BR + px;
         const bool mok = m < mend;
 #pragma unroll
         for (int c = 0; c < CPTA; ++c) {
             const int ch = tq * CPTA + c;
             const int co = co0 + ch * V;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (mok && ch < ACH && co < p.ldd) v = *reinterpret_cast<const uint4*>((const T*)p.dy + (size_t)m * p.ldd + co);
-            ra[c] = v;
+            const unsigned od = (mok && ch < ACH && co < p.ldd) ? (unsigned)(m * p.ldd + co) * (unsigned)sizeof(T) : kOOB;
+            ra[st][c] = buf_load16(rsd, od);
         }
         const int ih0 = poh * g.stride - g.pad, iw0 = pow_ * g.stride - g.pad;
+        if (SRC == SRC_1X1) {
+            const unsigned rowoff = (unsigned)(((pn * g.H0 + ih0) * g.W0 + iw0) * g.C0) * (unsigned)sizeof(T);
 #pragma unroll
-        for (int c = 0; c < CPTB; ++c) {
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (mok && bci[c] >= 0) {
-                const T* ptr = gather_ptr<T>(g, pn, ih0 + bkh[c], iw0 + bkw[c], bci[c]);
-                if (ptr) v = *reinterpret_cast<const uint4*>(ptr);
+            for (int c = 0; c < CPTB; ++c)
+                rb[st][c] = buf_load16(rs0, (mok && bci[c] >= 0) ? rowoff + (unsigned)bci[c] * (unsigned)sizeof(T) : kOOB);
+        } else if (ONE_TAP) {
+            unsigned o0, o1;
+            gather_off<T, SRC>(g, mok && bci[0] >= 0, pn, ih0 + bkh[0], iw0 + bkw[0], bci[0], o0, o1);
+#pragma unroll
+            for (int c = 0; c < CPTB; ++c) {
+                uint4 v = buf_load16(rs0, o0 + 16u * c);
+                if (mode == SDE_SRC_UPCAT) {
+                    const uint4 u = buf_load16(rs1, o1 + 16u * c);
+                    v.x |= u.x; v.y |= u.y; v.z |= u.z; v.w |= u.w;
+                }
+                rb[st][c] = v;
             }
-            rb[c] = v;
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPTB; ++c) {
+                unsigned o0, o1;
+                gather_off<T, SRC>(g, mok && bci[c] >= 0, pn, ih0 + bkh[c], iw0 + bkw[c], bci[c], o0, o1);
+                uint4 v = buf_load16(rs0, o0);
+                if (mode == SDE_SRC_UPCAT) {
+                    const uint4 u = buf_load16(rs1, o1);
+                    v.x |= u.x; v.y |= u.y; v.z |= u.z; v.w |= u.w;
+                }
+                rb[st][c] = v;
+            }
         }
         pow_ += BR;
         while (pow_ >= g.OW) { pow_ -= g.OW; if (++poh == g.OH) { poh = 0; ++pn; } }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, auto SET) {
+        constexpr int st = decltype(SET)::value;
 #pragma unroll
         for (int c = 0; c < CPTA; ++c) {
             const int ch = tq * CPTA + c;
-            if (ch < ACH) *reinterpret_cast<uint4*>(sA + (size_t)(buf * BR + px) * STRA + ch * 16) = ra[c];
+            if (ch < ACH) *reinterpret_cast<uint4*>(sA + (size_t)(buf * BR + px) * STRA + ((ch * 16) ^ (SWZ * ((px & 8) << 4)))) = ra[st][c];
         }
 #pragma unroll
-        for (int c = 0; c < CPTB; ++c) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BR + px) * STRB + (tq * CPTB + c) * 16) = rb[c];
+        for (int c = 0; c < CPTB; ++c)
+            *reinterpret_cast<uint4*>(sB + (size_t)(buf * BR + px) * STRB + (((tq * CPTB + c) * 16) ^ (SWZ * ((px & 8) << 4)))) = rb[st][c];
     };
 
     f32x4 acc[FM][FN];
@@ -457,14 +587,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(WGradP p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ns = (mend - mbeg + BR - 1) / BR;
-    if (ns > 0) {
-        load_stage(0);
-        store_stage(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < ns; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < ns) load_stage(s + 1);
+    auto compute_stage = [&](int buf) {
         const unsigned char* tA = sA + (size_t)buf * BR * STRA;
         const unsigned char* tB = sB + (size_t)buf * BR * STRB;
 #pragma unroll
@@ -479,8 +602,23 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_kernel(WGradP p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = mma64<T>(a[i], b[j], acc[i][j]);
         }
-        if (s + 1 < ns) store_stage(buf ^ 1);
+    };
+    auto step = [&](int st, auto CUR, auto NXT) {
+        if (st >= ns) return;
+        if (st + 3 < ns) load_stage(st + 3, CUR);
+        compute_stage(st & 1);
+        if (st + 1 < ns) store_stage((st + 1) & 1, NXT);
         __syncthreads();
+    };
+    if (ns > 0) load_stage(0, IC<0>{});
+    if (ns > 1) load_stage(1, IC<1>{});
+    if (ns > 2) load_stage(2, IC<2>{});
+    if (ns > 0) store_stage(0, IC<0>{});
+    __syncthreads();
+    for (int s = 0; s < ns; s += 3) {
+        step(s, IC<0>{}, IC<1>{});
+        step(s + 1, IC<1>{}, IC<2>{});
+        step(s + 2, IC<2>{}, IC<0>{});
     }
     // slab[split][co][k]
     const int fr = lane & 15, fg = lane >> 4;
@@ -605,18 +743,18 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const sde_pack_item* 
 // ------------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int SRC, bool ONE_TAP>
 int launch_igemm(const IGemmP& p, hipStream_t s) {
     constexpr int stage = 2 * (BM + BN) * KSTAGE_BYTES;
     constexpr int ctile = BM * (BN + 4) * 4;
     constexpr int lds = stage > ctile ? stage : ctile;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, SRC, ONE_TAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     dim3 grid(sde_cdiv(p.g.M, BM) * sde_cdiv(p.ldy, BN));
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), grid, dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, SRC, ONE_TAP>), grid, dim3(NTHREADS), lds, s, p);
     return 0;
 }
 
@@ -630,29 +768,69 @@ int pick_tile(long M, int N) {
     return 128016;
 }
 
-template <typename T>
-int dispatch_igemm(const IGemmP& p, hipStream_t s) {
-    switch (pick_tile(p.g.M, p.ldy)) {
-        case 128128: return launch_igemm<T, 128, 128, 2, 2>(p, s);
-        case 128064: return launch_igemm<T, 128, 64, 2, 2>(p, s);
-        case 128032: return launch_igemm<T, 128, 32, 4, 1>(p, s);
-        case 128016: return launch_igemm<T, 128, 16, 4, 1>(p, s);
-        default: return launch_igemm<T, 64, 64, 2, 2>(p, s);
+// which specialisation of the gather a descriptor gets (bf16); fp32 (parity mode) keeps the run-time generic kernel
+int src_kind(const Gather& g) {
+    if (g.mode == SDE_SRC_UPCAT) return SRC_UPCAT_REFLECT;
+    if (g.mode == SDE_SRC_ZEROINS) return SRC_ZEROINS_ZERO;
+    if (g.KH == 1 && g.KW == 1 && g.pad == 0 && !g.reflect) return SRC_1X1;
+    return g.reflect ? SRC_PLAIN_REFLECT : SRC_PLAIN_ZERO;
+}
+bool one_tap_ok(const Gather& g, int group) {      // group = elements covered by one thread per stage
+    return (g.Cin % group == 0) && (g.mode != SDE_SRC_UPCAT || g.C0 % group == 0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int dispatch_src(const IGemmP& p, hipStream_t s) {
+    constexpr int group = (8 / (NTHREADS / BM)) * VecOf<T>::V;
+    if (sizeof(T) == 4 || (p.g.mode == SDE_SRC_UPCAT && !p.g.reflect) || (p.g.mode == SDE_SRC_ZEROINS && p.g.reflect))
+        return launch_igemm<T, BM, BN, WM, WN, SRC_RUNTIME, false>(p, s);
+    const bool ot = one_tap_ok(p.g, group);
+    switch (src_kind(p.g)) {
+        case SRC_1X1: return launch_igemm<T, BM, BN, WM, WN, SRC_1X1, true>(p, s);
+        case SRC_PLAIN_ZERO: return ot ? launch_igemm<T, BM, BN, WM, WN, SRC_PLAIN_ZERO, true>(p, s) : launch_igemm<T, BM, BN, WM, WN, SRC_PLAIN_ZERO, false>(p, s);
+        case SRC_PLAIN_REFLECT: return ot ? launch_igemm<T, BM, BN, WM, WN, SRC_PLAIN_REFLECT, true>(p, s) : launch_igemm<T, BM, BN, WM, WN, SRC_PLAIN_REFLECT, false>(p, s);
+        case SRC_UPCAT_REFLECT: return ot ? launch_igemm<T, BM, BN, WM, WN, SRC_UPCAT_REFLECT, true>(p, s) : launch_igemm<T, BM, BN, WM, WN, SRC_UPCAT_REFLECT, false>(p, s);
+        default: return ot ? launch_igemm<T, BM, BN, WM, WN, SRC_ZEROINS_ZERO, true>(p, s) : launch_igemm<T, BM, BN, WM, WN, SRC_ZEROINS_ZERO, false>(p, s);
     }
 }
 
-template <typename T, int BMG, int BNG, int WM, int WN>
+template <typename T>
+int dispatch_igemm(const IGemmP& p, hipStream_t s) {
+    switch (pick_tile(p.g.M, p.ldy)) {
+        case 128128: return dispatch_src<T, 128, 128, 2, 2>(p, s);
+        case 128064: return dispatch_src<T, 128, 64, 2, 2>(p, s);
+        case 128032: return dispatch_src<T, 128, 32, 4, 1>(p, s);
+        case 128016: return dispatch_src<T, 128, 16, 4, 1>(p, s);
+        default: return dispatch_src<T, 64, 64, 2, 2>(p, s);
+    }
+}
+
+template <typename T, int BMG, int BNG, int WM, int WN, int SRC, bool ONE_TAP>
 int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
     constexpr int BR = WGTraits<T>::BR;
-    constexpr int lds = 2 * BR * (BMG * (int)sizeof(T) + 16) + 2 * BR * (BNG * (int)sizeof(T) + 16);
+    constexpr int lds = sizeof(T) == 2 ? 4 * BR * 288 : 2 * BR * (BMG * (int)sizeof(T) + 16) + 2 * BR * (BNG * (int)sizeof(T) + 16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMG, BNG, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMG, BNG, WM, WN, SRC, ONE_TAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     dim3 grid(sde_cdiv(p.Cout, BMG) * sde_cdiv(p.g.Ktot, BNG) * splits);
-    hipLaunchKernelGGL((wgrad_kernel<T, BMG, BNG, WM, WN>), grid, dim3(NTHREADS), lds, s, p);
+    hipLaunchKernelGGL((wgrad_kernel<T, BMG, BNG, WM, WN, SRC, ONE_TAP>), grid, dim3(NTHREADS), lds, s, p);
     return 0;
+}
+
+template <typename T, int BMG, int BNG, int WM, int WN>
+int dispatch_wsrc(const WGradP& p, int splits, hipStream_t s) {
+    constexpr int group = 4 * VecOf<T>::V;     // CPTB chunks of V elements
+    if (sizeof(T) == 4 || (p.g.mode == SDE_SRC_UPCAT && !p.g.reflect) || p.g.mode == SDE_SRC_ZEROINS)
+        return launch_wgrad<T, BMG, BNG, WM, WN, SRC_RUNTIME, false>(p, splits, s);
+    const bool ot = one_tap_ok(p.g, group);
+    switch (src_kind(p.g)) {
+        case SRC_1X1: return launch_wgrad<T, BMG, BNG, WM, WN, SRC_1X1, true>(p, splits, s);
+        case SRC_PLAIN_ZERO: return ot ? launch_wgrad<T, BMG, BNG, WM, WN, SRC_PLAIN_ZERO, true>(p, splits, s) : launch_wgrad<T, BMG, BNG, WM, WN, SRC_PLAIN_ZERO, false>(p, splits, s);
+        case SRC_PLAIN_REFLECT: return ot ? launch_wgrad<T, BMG, BNG, WM, WN, SRC_PLAIN_REFLECT, true>(p, splits, s) : launch_wgrad<T, BMG, BNG, WM, WN, SRC_PLAIN_REFLECT, false>(p, splits, s);
+        default: return ot ? launch_wgrad<T, BMG, BNG, WM, WN, SRC_UPCAT_REFLECT, true>(p, splits, s) : launch_wgrad<T, BMG, BNG, WM, WN, SRC_UPCAT_REFLECT, false>(p, splits, s);
+    }
 }
 
 int wgrad_bmg(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : (Cout > 16 ? 32 : 16)); }
@@ -660,10 +838,10 @@ int wgrad_bmg(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : (Cout > 16 
 template <typename T>
 int dispatch_wgrad(const WGradP& p, int splits, hipStream_t s) {
     switch (wgrad_bmg(p.Cout)) {
-        case 128: return launch_wgrad<T, 128, 128, 2, 2>(p, splits, s);
-        case 64: return launch_wgrad<T, 64, 128, 1, 4>(p, splits, s);
-        case 32: return launch_wgrad<T, 32, 128, 1, 4>(p, splits, s);
-        default: return launch_wgrad<T, 16, 128, 1, 4>(p, splits, s);
+        case 128: return dispatch_wsrc<T, 128, 128, 2, 2>(p, splits, s);
+        case 64: return dispatch_wsrc<T, 64, 128, 1, 4>(p, splits, s);
+        case 32: return dispatch_wsrc<T, 32, 128, 1, 4>(p, splits, s);
+        default: return dispatch_wsrc<T, 16, 128, 1, 4>(p, splits, s);
     }
 }
 

@@ -152,12 +152,12 @@ template <int NV>
 __device__ __forceinline__ void block_group_reduce(float (&a)[NV], int cch, float* sh) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int e = 0; e < NV; ++e) sh[t * NV + e] = a[e];
+    for (int e = 0; e < NV; ++e) sh[e * 256 + t] = a[e];      // element-major: lanes hit consecutive banks
     __syncthreads();
     if (t < cch) {
         for (int r = t + cch; r < 256; r += cch)
 #pragma unroll
-            for (int e = 0; e < NV; ++e) a[e] += sh[r * NV + e];
+            for (int e = 0; e < NV; ++e) a[e] += sh[e * 256 + r];
     }
 }
 
@@ -774,9 +774,10 @@ int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu
     return SDE_OK;
 }
 
-int sde_reduce_num_blocks(long M) {
-    long nb = (M + 255) / 256;     // >= 256 rows per block
-    if (nb > 512) nb = 512;
+int sde_reduce_num_blocks(long M, int C) {
+    // ~4 sixteen-byte groups per thread (bf16 grouping), enough workgroups to keep HBM busy: these passes are pure streaming
+    long nb = (M * (long)C / 8 + 1023) / 1024;
+    if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -788,7 +789,7 @@ int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bn
     SDE_CHECK_ARG(!relu || out, "sde_bn_bwd: relu needs the saved output");
     (void)gamma;
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = sde_reduce_num_blocks(M);
+    const int nblk = sde_reduce_num_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     const size_t lds = (2 * (size_t)C > 256 * 16 ? 2 * (size_t)C : 256 * 16) * sizeof(float);
     DISPATCH_T(dtype,
@@ -838,7 +839,7 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
     SDE_CHECK_ARG(act == SDE_ACT_NONE || out, "sde_act_bwd_bias: activation backward needs the saved output");
     SDE_CHECK_ARG((dbias == nullptr) || (part && Cbias > 0 && Cbias <= C), "sde_act_bwd_bias: bias gradient needs a partial slab");
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = sde_reduce_num_blocks(M);
+    const int nblk = sde_reduce_num_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     float* p = dbias ? part : nullptr;
     const size_t lds = ((size_t)C > 256 * 8 ? (size_t)C : 256 * 8) * sizeof(float);

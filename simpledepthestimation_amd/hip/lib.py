@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size
 import torch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_HERE, "libsde_hip.so")
+LIB_PATH = os.environ.get("SDE_HIP_LIB", os.path.join(_HERE, "libsde_hip.so"))   # override: A/B builds of the same ABI
 MAX_CTX = 4
 F32, BF16 = 0, 1
 

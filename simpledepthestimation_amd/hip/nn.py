@@ -34,7 +34,7 @@ L.register_protos({
     "sde_bn_finalize": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P], c_int),
     "sde_bn_eval_params": ([_P, _P, _P, _P, _F, _I, _P, _P], c_int),
     "sde_bn_apply": ([_P, _P, _P, _I, _LG, _I, _I, _P, _P], c_int),
-    "sde_reduce_num_blocks": ([_LG], c_int),
+    "sde_reduce_num_blocks": ([_LG, _I], c_int),
     "sde_bn_bwd": ([_P, _P, _P, _P, _P, _I, _LG, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P], c_int),
     "sde_maxpool_fwd": ([_P, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
     "sde_maxpool_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
@@ -139,6 +139,7 @@ def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device, kin
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, stride, pad, reflect, act, upcat, want_stats, owner=None):
+        ctx.set_materialize_grads(False)      # the statistics output never carries a gradient: do not launch zero fills for it
         if not x0.is_contiguous() or (x1 is not None and not x1.is_contiguous()):
             raise L.SdeHipError("conv2d: NHWC inputs must be contiguous")
         dt = x0.dtype
@@ -185,6 +186,8 @@ class _Conv2d(torch.autograd.Function):
         C1 = x1.shape[3] if x1 is not None else 0
         Cout, Cin, KH, KW = weight.shape
         ldy = pad_to(Cout, V)
+        if dy is None:
+            return (None,) * 11
         dy = dy.contiguous()
         M = B * OH * OW
         flops = 2.0 * M * Cout * KH * KW * Cin                    # algorithmic FLOPs of each of dgrad / wgrad
@@ -192,7 +195,7 @@ class _Conv2d(torch.autograd.Function):
         dbias = None
         dz = dy
         if act != ACT_NONE or has_bias:
-            nblk = lib.sde_reduce_num_blocks(M)
+            nblk = lib.sde_reduce_num_blocks(M, ldy)
             part = torch.empty(nblk + REDUCE_ROWS, ldy, device=dev) if has_bias else None
             bslot = _grad_slot(ctx.params[1]) if has_bias else None
             dbias = (bslot if bslot is not None else torch.empty(Cout, device=dev)) if has_bias else None
@@ -335,7 +338,7 @@ class _BatchNormAct(torch.autograd.Function):
         lib = L.lib()
         dev = y.device
         dout = dout.contiguous()
-        part = torch.empty(lib.sde_reduce_num_blocks(M) + REDUCE_ROWS, C, 2, device=dev)
+        part = torch.empty(lib.sde_reduce_num_blocks(M, C) + REDUCE_ROWS, C, 2, device=dev)
         coef = torch.empty(2, C, device=dev)
         gs, bs = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
         direct = gs is not None and bs is not None
