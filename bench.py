@@ -64,7 +64,7 @@ def build(args, device):
     torch.manual_seed(0)
     model = build_model(cfg).train()
     mk = T.supervised_trainer if wl["arch"] == "SupDepthModel" else T.monodepth2_trainer
-    trainer = mk(model, cfg, use_graph=not args.no_graph)
+    trainer = mk(model, cfg, use_graph=not args.no_graph, overlap=(True if args.force_overlap else None))
     return cfg, model, trainer
 
 
@@ -153,18 +153,25 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-overlap", action="store_true", help="use the two-phase backward (all-reduce overlap path) even on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev            # ranks > devices only in the single-GPU rehearsal below
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        backend = os.environ.get("SDE_DIST_BACKEND", "nccl")      # "nccl" IS RCCL on ROCm; "gloo" lets 2 ranks rehearse on ONE GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
     cfg, model, trainer = build(args, device)
@@ -199,7 +206,7 @@ def main():
                "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": f"{WORKLOADS[args.workload]['desc']}, {args.dtype} storage / fp32 accumulate, bs={args.batch}/GPU, "
                                       f"{args.height}x{args.width}, fwd+bwd+optimizer, random-init weights", "global_batch": args.batch * world,
-                          "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                          "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "allreduce_overlap": bool(trainer.overlap)},
                "final_losses": final}
         if args.profile_steps > 0:
             out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype)

@@ -364,46 +364,56 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
                 sC[row * (BN + CPAD) + col] = acc[i][j][r];
             }
     __syncthreads();
-    constexpr int CCH = BN / V;   // 16-byte chunks per output row
-    const bool vec_ok = (p.ldy % V) == 0;
-    for (int id = tid; id < BM * CCH; id += NTHREADS) {
-        const int row = id / CCH, c0 = (id - row * CCH) * V;
+    // float4 groups: consecutive lanes read consecutive 16 B of the staging tile (conflict-free ds_read_b128) and write
+    // consecutive 4-element groups of the NHWC row (a wave instruction covers whole 128-byte lines)
+    constexpr int G4 = BN / 4;
+    const bool vec_ok = (p.ldy % 4) == 0;
+    for (int id = tid; id < BM * G4; id += NTHREADS) {
+        const int row = id / G4, c0 = (id - row * G4) * 4;
         const int m = m0 + row, n = n0 + c0;
         if (m >= g.M || n >= p.ldy) continue;
-        float v[V];
+        const float4 q = *reinterpret_cast<const float4*>(&sC[row * (BN + CPAD) + c0]);
+        float v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            float t = sC[row * (BN + CPAD) + c0 + e];
+        for (int e = 0; e < 4; ++e) {
+            float t = v[e];
             if (p.bias && n + e < p.Cout) t += p.bias[n + e];
             if (p.act == SDE_ACT_ELU) t = t > 0.f ? t : expm1f(t);
             if (n + e >= p.Cout) t = 0.f;     // padded output channels are exact zeros
             v[e] = t;
         }
         T* dst = (T*)p.y + (size_t)m * p.ldy + n;
-        if (vec_ok && n + V <= p.ldy) {
-            T o[V];
+        T o[4];
 #pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = from_f32<T>(v[e]);
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(o);
+        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+        if (vec_ok && n + 4 <= p.ldy) {
+            if (sizeof(T) == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(o);
+            else *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(o);
         } else {
-            for (int e = 0; e < V && n + e < p.ldy; ++e) dst[e] = from_f32<T>(v[e]);
+            for (int e = 0; e < 4 && n + e < p.ldy; ++e) dst[e] = o[e];
         }
-        if (p.stats) {   // keep the rounded value for the statistics pass
-#pragma unroll
-            for (int e = 0; e < V; ++e) sC[row * (BN + CPAD) + c0 + e] = to_f32<T>(from_f32<T>(v[e]));
-        }
+        if (p.stats)     // keep the rounded value for the statistics pass
+            *reinterpret_cast<float4*>(&sC[row * (BN + CPAD) + c0]) = make_float4(to_f32<T>(o[0]), to_f32<T>(o[1]), to_f32<T>(o[2]), to_f32<T>(o[3]));
     }
     if (p.stats) {
         __syncthreads();
-        // per-tile column sums of y and y^2 over the valid rows (what BatchNorm's batch statistics need)
-        for (int c = tid; c < BN; c += NTHREADS) {
-            const int n = n0 + c;
-            if (n >= p.Cout) continue;
-            const int rows = min(BM, g.M - m0);
-            float s1 = 0.f, s2 = 0.f;
-            for (int r = 0; r < rows; ++r) { const float t = sC[r * (BN + CPAD) + c]; s1 += t; s2 += t * t; }
-            p.stats[((size_t)tile_m * p.Cout + n) * 2 + 0] = s1;
-            p.stats[((size_t)tile_m * p.Cout + n) * 2 + 1] = s2;
+        // per-tile column sums of y and y^2 over the valid rows (what BatchNorm's batch statistics need); the 256 threads split
+        // each column's rows into NTHREADS/BN interleaved parts that are combined through the (now free) staging buffers' tail
+        constexpr int PARTS = NTHREADS / BN >= 1 ? NTHREADS / BN : 1;
+        float* red = sC + BM * (BN + CPAD);                    // [PARTS][BN][2] behind the tile (allocated by launch_igemm)
+        const int c = tid % BN, part = tid / BN;
+        const int rows = min(BM, g.M - m0);
+        float s1 = 0.f, s2 = 0.f;
+        if (part < PARTS)
+            for (int r = part; r < rows; r += PARTS) { const float t = sC[r * (BN + CPAD) + c]; s1 += t; s2 += t * t; }
+        if (part < PARTS) { red[(part * BN + c) * 2] = s1; red[(part * BN + c) * 2 + 1] = s2; }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Cout) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) { a += red[(q * BN + tid) * 2]; b += red[(q * BN + tid) * 2 + 1]; }
+            p.stats[((size_t)tile_m * p.Cout + n0 + tid) * 2 + 0] = a;
+            p.stats[((size_t)tile_m * p.Cout + n0 + tid) * 2 + 1] = b;
         }
     }
 }
@@ -746,7 +756,7 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const sde_pack_item* 
 template <typename T, int BM, int BN, int WM, int WN, int SRC, bool ONE_TAP>
 int launch_igemm(const IGemmP& p, hipStream_t s) {
     constexpr int stage = 2 * (BM + BN) * KSTAGE_BYTES;
-    constexpr int ctile = BM * (BN + 4) * 4;
+    constexpr int ctile = BM * (BN + 4) * 4 + NTHREADS * 2 * 4;      // staging tile + per-part column sums
     constexpr int lds = stage > ctile ? stage : ctile;
     static bool attr_done = false;
     if (!attr_done) {

@@ -88,17 +88,28 @@ __global__ void __launch_bounds__(1024) rows_reduce_kernel(const float* __restri
     }
 }
 
+// Sum over the 32 lanes of a half-wave (the finalize kernels spread the <= SDE_REDUCE_ROWS partial rows over 32 lanes, so every
+// row is one independent load instead of a serial chain of dependent loads).  Fixed shuffle order: deterministic.
+__device__ __forceinline__ double half_wave_sum(double v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // BatchNorm
 // ------------------------------------------------------------------------------------------------------------------
 // bnp layout: [4][C] = mean, rstd, scale (= gamma*rstd), shift (= beta - mean*scale)
-__global__ void __launch_bounds__(64) bn_finalize_kernel(const float* __restrict__ part, int tiles, int C, float count, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                         float momentum, float eps, float* __restrict__ bnp) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ part, int tiles, int C, float count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          float momentum, float eps, float* __restrict__ bnp) {
+    // 256 threads = 8 channels x 32 row lanes (tiles <= SDE_REDUCE_ROWS after the pre-reduction)
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
     double s1 = 0, s2 = 0;
-    for (int t = 0; t < tiles; ++t) { s1 += part[((size_t)t * C + c) * 2]; s2 += part[((size_t)t * C + c) * 2 + 1]; }
+    if (c < C)
+        for (int t = r; t < tiles; t += 32) { s1 += part[((size_t)t * C + c) * 2]; s2 += part[((size_t)t * C + c) * 2 + 1]; }
+    s1 = half_wave_sum(s1); s2 = half_wave_sum(s2);
+    if (c >= C || r != 0) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
@@ -225,12 +236,14 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // coef layout [2][C]: mean(dz), mean(dz*xhat); also dgamma (+)=, dbeta (+)=
-__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float count, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float count, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
     double s1 = 0, s2 = 0;
-    for (int t = 0; t < nblk; ++t) { s1 += part[((size_t)t * C + c) * 2]; s2 += part[((size_t)t * C + c) * 2 + 1]; }
+    if (c < C)
+        for (int t = r; t < nblk; t += 32) { s1 += part[((size_t)t * C + c) * 2]; s2 += part[((size_t)t * C + c) * 2 + 1]; }
+    s1 = half_wave_sum(s1); s2 = half_wave_sum(s2);
+    if (c >= C || r != 0) return;
     coef[c] = (float)(s1 / count); coef[C + c] = (float)(s2 / count);
     dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
@@ -408,11 +421,13 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(64) colsum_finalize_kernel(const float* __restrict__ part, int nblk, int ld, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ part, int nblk, int ld, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
     double s = 0;
-    for (int t = 0; t < nblk; ++t) s += part[(size_t)t * ld + c];
+    if (c < C)
+        for (int t = r; t < nblk; t += 32) s += part[(size_t)t * ld + c];
+    s = half_wave_sum(s);
+    if (c >= C || r != 0) return;
     out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
@@ -749,7 +764,7 @@ int sde_bn_finalize(const float* part, int tiles, int C, long count, const float
     SDE_CHECK_ARG(part && gamma && beta && bnp && tiles > 0 && C > 0 && count > 0, "sde_bn_finalize: bad argument");
     int rows = tiles;
     const float* src = pre_reduce(part, rows, 2 * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, src, rows, C, (float)count, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, src, rows, C, (float)count, gamma, beta, running_mean,
                        running_var, momentum, eps, bnp);
     SDE_CHECK_LAUNCH("sde_bn_finalize");
     return SDE_OK;
@@ -798,7 +813,7 @@ int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bn
     SDE_CHECK_LAUNCH("sde_bn_bwd/reduce");
     int rows = nblk;
     const float* src = pre_reduce(part, rows, 2 * C, s);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 64)), dim3(64), 0, s, src, rows, C, (float)M, dgamma, dbeta, accumulate_params, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(256), 0, s, src, rows, C, (float)M, dgamma, dbeta, accumulate_params, coef);
     SDE_CHECK_LAUNCH("sde_bn_bwd/finalize");
     const int nb = grid_for(M * (C / V));
     DISPATCH_T(dtype,
@@ -850,7 +865,7 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
     if (dbias) {
         int rows = nblk;
         const float* src = pre_reduce(part, rows, C, s);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sde_cdiv(Cbias, 64)), dim3(64), 0, s, src, rows, C, Cbias, dbias, accumulate);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sde_cdiv(Cbias, 8)), dim3(256), 0, s, src, rows, C, Cbias, dbias, accumulate);
         SDE_CHECK_LAUNCH("sde_act_bwd_bias/finalize");
     }
     return SDE_OK;

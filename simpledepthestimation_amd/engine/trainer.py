@@ -32,11 +32,30 @@ class ParamGroup:
         self.name, self.named_params, self.lr, self.weight_decay = name, list(named_params), float(lr), float(weight_decay)
 
 
+class GradCut:
+    """Splits the autograd graph at a set of activations (the encoder features feeding layer3 and the decoder skips).
+
+    forward: cut(feats) returns detached leaves that the "late" part of the network consumes; phase A's loss.backward() then stops at
+    the leaves (filling leaf.grad) after producing every late parameter gradient; phase B continues from the original tensors.
+    """
+
+    def __init__(self):
+        self.orig, self.leaves = None, None
+
+    def __call__(self, feats):
+        self.orig = list(feats)
+        self.leaves = [f.detach().requires_grad_(True) for f in feats]
+        return self.leaves
+
+    def backward_rest(self):
+        torch.autograd.backward(self.orig, [l.grad for l in self.leaves])
+
+
 class HipTrainer:
     """Owns the flat buffers and runs one training step: loss dict = trainer.step(batch)."""
 
     def __init__(self, model, groups, adamw=False, betas=(0.9, 0.999), eps=1e-8, bucket_mb=64, use_graph=False, skip_unused=(".fc.",),
-                 adam_fn=None):
+                 adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None):
         self.model = model
         self._adam_fn = adam_fn or HN.adam_step      # tests on CPU (gloo) substitute a torch restatement of the same update
         self.adamw, self.betas, self.eps = bool(adamw), betas, float(eps)
@@ -75,6 +94,23 @@ class HipTrainer:
         self.buckets = [(s, min(total, s + per)) for s in range(0, total, per)]
         if self.world > 1:
             dist.broadcast(self.pflat, src=0)          # DDP's initial parameter broadcast (setup.py:L40)
+        # ---- two-phase backward (overlap the all-reduce of the "late" parameters with the rest of backward)
+        owner = cut_owner if cut_owner is not None else getattr(model, "depth_net", None)
+        self.overlap = (self.world > 1) if overlap is None else bool(overlap)
+        self._cut, self.late_start = None, total
+        if self.overlap and owner is not None and hasattr(owner, "_grad_cut"):
+            off = 0
+            for g in self.groups:
+                for n, p in g.named_params:
+                    if self.late_start == total and any(t in n for t in late_from):
+                        self.late_start = off
+                    off += p.numel()
+            if self.late_start < total:
+                self._cut = GradCut()
+                owner._grad_cut = self._cut
+        if self._cut is None:
+            self.overlap = False
+        self._graph_b = None
         self._graph = None
         self._static_batch = None
         self._static_out = None
@@ -103,12 +139,20 @@ class HipTrainer:
                 self.batch_pack = False             # model without HIP convolutions
         return loss_dict
 
-    def _allreduce(self):
+    def _allreduce(self, lo=0, hi=None, wait=True):
+        """SUM all-reduce of gflat[lo:hi] in buckets; returns the work handles (already waited on unless wait=False)."""
         if self.world == 1:
-            return
-        handles = [dist.all_reduce(self.gflat[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in self.buckets]
-        for h in handles:
-            h.wait()
+            return []
+        hi = self.numel if hi is None else hi
+        handles = []
+        for a, b in self.buckets:
+            a, b = max(a, lo), min(b, hi)
+            if a < b:
+                handles.append(dist.all_reduce(self.gflat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        if wait:
+            for h in handles:
+                h.wait()
+        return handles
 
     def _optimizer(self):
         self.t += 1
@@ -146,11 +190,17 @@ class HipTrainer:
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 self._fwd_bwd(dict(self._static_batch))
+                if self._cut is not None:
+                    self._cut.backward_rest()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._static_out = self._fwd_bwd(dict(self._static_batch))
+        if self._cut is not None:                  # phase B: the rest of backward, same memory pool, replayed after phase A
+            self._graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_b, pool=self._graph.pool()):
+                self._cut.backward_rest()
         return self
 
     def step(self, batch):
@@ -163,7 +213,18 @@ class HipTrainer:
             loss_dict = self._static_out
         else:
             loss_dict = self._fwd_bwd(batch)
-        self._allreduce()
+        if self._cut is None:
+            self._allreduce()
+        else:
+            # phase A is done: every gradient from late_start on is final -> reduce it while phase B (high-resolution layers) runs
+            late = self._allreduce(self.late_start, self.numel, wait=False)
+            if self._graph_b is not None:
+                self._graph_b.replay()
+            else:
+                self._cut.backward_rest()
+            early = self._allreduce(0, self.late_start, wait=False)
+            for h in late + early:
+                h.wait()
         self._optimizer()
         return loss_dict
 

@@ -97,6 +97,19 @@ def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_side = {}
+SIDE_STREAM = os.environ.get("SDE_WGRAD_SIDE_STREAM", "1") != "0"
+
+
+def side_stream():
+    """Per-device helper stream: weight-gradient GEMMs run on it concurrently with the data-gradient GEMM of the same layer
+    (fork/join with stream waits, so it is captured into the step's hipGraph as a parallel branch)."""
+    d = torch.cuda.current_device()
+    if d not in _side:
+        _side[d] = torch.cuda.Stream(device=d)
+    return _side[d]
+
+
 def ptr_array(tensors):
     arr = (c_void_p * MAX_CTX)()
     for i, t in enumerate(tensors):

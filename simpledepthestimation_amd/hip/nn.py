@@ -206,21 +206,35 @@ class _Conv2d(torch.autograd.Function):
                 dbias = None
             if dz is None:
                 dz = dy
-        # 2. weight gradient
+        # 2. weight gradient -- on the side stream when a data gradient follows, so the two independent GEMMs overlap
         dw = None
+        need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
+        forked = False
         if ctx.needs_input_grad[2]:
             d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
             splits = lib.sde_conv_wgrad_splits(ctypes.byref(d), Cout)
-            slab = torch.empty(splits + 16, Cout, KH * KW * (C0 + C1), device=dev)       # + SDE_WGRAD_FOLD_ROWS scratch rows
             wslot = _grad_slot(ctx.params[0])
-            dw = wslot if wslot is not None else torch.empty_like(weight)
             meta = None
             if L.PROFILE is not None:
                 esz = 2 if dt == torch.bfloat16 else 4
                 meta = dict(M=M, N=Cout, K=KH * KW * (C0 + C1), k=KH, s=stride, mode=int(upcat), splits=splits,
                             bytes=esz * (B * H0 * W0 * C0 + B * IH * IW * C1 + M * ldy) + 8 * splits * Cout * KH * KW * (C0 + C1))
-            _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
-                                                                         int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
+            forked = need_dx and L.SIDE_STREAM and L.PROFILE is None
+            cur = torch.cuda.current_stream()
+            if forked:
+                side = L.side_stream()
+                side.wait_stream(cur)
+                wctx = torch.cuda.stream(side)
+            else:
+                import contextlib
+                wctx = contextlib.nullcontext()
+            with wctx:
+                slab = torch.empty(splits + 16, Cout, KH * KW * (C0 + C1), device=dev)       # + SDE_WGRAD_FOLD_ROWS scratch rows
+                dw = wslot if wslot is not None else torch.empty_like(weight)
+                _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
+                                                                             int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
+                if forked:
+                    slab.record_stream(side)
             if wslot is not None:
                 dw = None
         # 3. data gradient
@@ -245,6 +259,8 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     raise L.SdeHipError(f"stride {stride} not supported")
                 dx0, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
+        if forked:
+            torch.cuda.current_stream().wait_stream(side)       # join: dz / x0 / x1 stay alive until both GEMMs are done
         return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
 
 

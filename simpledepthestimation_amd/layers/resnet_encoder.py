@@ -96,12 +96,17 @@ class ResnetEncoder(nn.Module):
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
-    def forward(self, x):
-        """x: NHWC normalised image (channels padded).  Returns the 5 NHWC feature maps."""
+    def forward(self, x, cut=None):
+        """x: NHWC normalised image (channels padded).  Returns the 5 NHWC feature maps.
+        cut (optional): callable(list_of_3_features) -> list of 3 detached leaves; layer3/layer4 then consume the leaves, so a
+        backward pass from the loss stops there (HipTrainer's two-phase backward)."""
         e = self.encoder
-        self.features = [conv_bn(e.conv1, e.bn1, x)]
-        self.features.append(e.layer1(HN.max_pool_3x3_s2(self.features[-1])))
-        self.features.append(e.layer2(self.features[-1]))
-        self.features.append(e.layer3(self.features[-1]))
-        self.features.append(e.layer4(self.features[-1]))
+        f0 = conv_bn(e.conv1, e.bn1, x)
+        f1 = e.layer1(HN.max_pool_3x3_s2(f0))
+        f2 = e.layer2(f1)
+        if cut is not None:
+            f0, f1, f2 = cut([f0, f1, f2])
+        f3 = e.layer3(f2)
+        f4 = e.layer4(f3)
+        self.features = [f0, f1, f2, f3, f4]
         return self.features

@@ -32,6 +32,9 @@ class DepthResNet(nn.Module):
         self.min_depth, self.max_depth = 0.1, float(cfg.MODEL.MAX_DEPTH)
         self.upsample_depth = cfg.MODEL.DEPTH_NET.UPSAMPLE_DEPTH
         self.dtype = compute_dtype(cfg)
+        # optional callable installed by engine.trainer.HipTrainer(overlap=True): splits the autograd graph at the encoder features
+        # so that the backward of decoder/layer4/layer3 (most parameters) finishes first and its all-reduce overlaps the rest
+        self._grad_cut = None
 
     def forward(self, batch):
         """Consumes batch['depth_net_input'] ([B,3,H,W] normalised, as in the reference) or the fused NHWC form the meta-archs of
@@ -40,7 +43,8 @@ class DepthResNet(nn.Module):
         x = batch.get("depth_net_input_nhwc")
         if x is None:
             x = HN.prep_input(batch["depth_net_input"], None, None, self.dtype, flip)   # flip folded into the layout change
-        feats = self.encoder(x)
+        cut = self._grad_cut if (self._grad_cut is not None and torch.is_grad_enabled()) else None
+        feats = self.encoder(x, cut=cut)
         logits = self.decoder(feats)
         disps = [HN.depth_head(logits[("disp_logit", i)], self.min_depth, self.max_depth, flip) for i in range(4)]
         if self.upsample_depth:
