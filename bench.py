@@ -96,7 +96,12 @@ def roofline_pass(trainer, batch, steps, dtype):
     peak = MFMA_PEAK_TFLOPS[dtype]
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     tot_ms = sum(f["ms"] for f in fam.values()); tot_fl = sum(f["flops"] for f in fam.values())
-    name = f"igemm_kernel<{dtype},{dom_key[1] // 1000}x{dom_key[1] % 1000}>" if dom_key[0] == "igemm" else "wgrad_kernel+wgrad_reduce_kernel"
+    if dom_key[0] != "igemm":
+        name = "wgrad_kernel+wgrad_reduce_kernel"
+    elif dom_key[1] >= 3000000:
+        name = f"halo3_kernel<{dtype},8x16 pixels x {dom_key[1] % 1000}>"
+    else:
+        name = f"igemm_kernel<{dtype},{dom_key[1] // 1000}x{dom_key[1] % 1000}>"
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
             "kernel": name, "launches_per_step": dom["launches"] // steps, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
             "gemm_flops_per_step": tot_fl / steps, "gemm_ms_per_step": round(tot_ms / steps, 3),

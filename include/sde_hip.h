@@ -149,7 +149,10 @@ int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total, 
 int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
                  sde_stream_t stream);
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy);
-int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy); /* tile the dispatcher picks: BM*1000 + BN (profiling aid) */
+int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy);
+/* Tuning / test knob: the LDS-halo 3x3 kernel is used when a launch has at least this many workgroups (default 192; 0 = whenever it
+ * applies, negative = never).  Returns the previous value.  Results do not depend on it beyond fp32 summation order. */
+int sde_conv_set_halo_min_blocks(int min_blocks); /* tile the dispatcher picks: BM*1000 + BN (profiling aid) */
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).
  * slab: caller workspace [splits + SDE_WGRAD_FOLD_ROWS][Cout][KH*KW*(C0+C1)] fp32, splits = sde_conv_wgrad_splits(d, Cout)

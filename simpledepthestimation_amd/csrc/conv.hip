@@ -419,6 +419,238 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with an LDS-resident halo tile ("LDS im2col"):  one workgroup = 8x16 output pixels.
+//   Per 64-channel block the (8+2)x(16+2) input pixels are staged in LDS ONCE; the nine filter taps are then nine shifted
+//   reads of that tile (address = base + tap offset), so the input crosses the vector-memory path 1.4x instead of 9x and the
+//   K loop carries no gather arithmetic at all -- only the small weight tiles stream per tap.  Same epilogue as igemm_kernel.
+//   Used for forward and data-gradient of every 3x3/1 layer whose output tiles well (see use_halo()).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2, HALO_PIX = (HT_H + 2) * HALO_W;   // 10 x 18 = 180 halo pixels
+constexpr int HPIX_STRIDE = 144;                                                        // 128 B of channels + 16 B pad
+constexpr int HALO_PASSES = (HALO_PIX * 8 + NTHREADS - 1) / NTHREADS;                   // 16-byte chunks per thread per block
+
+// byte offsets of halo pixel (ih, iw) of image n in source 0 / source 1 (channel 0), kOOB when it is padding
+template <typename T, int SRC>
+__device__ __forceinline__ void halo_pix(const Gather& g, bool ok, int n, int ih, int iw, unsigned& p0, unsigned& p1) {
+    if (src_reflect<SRC>(g)) { ih = reflect1(ih, g.IH); iw = reflect1(iw, g.IW); ok = ok & ((unsigned)ih < (unsigned)g.IH) & ((unsigned)iw < (unsigned)g.IW); }
+    else ok = ok & ((unsigned)ih < (unsigned)g.IH) & ((unsigned)iw < (unsigned)g.IW);
+    p1 = kOOB;
+    if (src_mode<SRC>(g) == SDE_SRC_UPCAT) {
+        p0 = ok ? (unsigned)(((n * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1)) * g.C0) * (unsigned)sizeof(T) : kOOB;
+        p1 = (ok && g.C1 > 0) ? (unsigned)(((n * g.IH + ih) * g.IW + iw) * g.C1) * (unsigned)sizeof(T) : kOOB;
+    } else {
+        p0 = ok ? (unsigned)(((n * g.H0 + ih) * g.W0 + iw) * g.C0) * (unsigned)sizeof(T) : kOOB;
+    }
+}
+
+template <typename T, int BN, int WM, int WN, int SRC>
+__global__ void __launch_bounds__(NTHREADS, 2) halo3_kernel(IGemmP p) {
+    constexpr int V = VecOf<T>::V;
+    constexpr int BM = HT_H * HT_W;                  // 128 output pixels
+    constexpr int BK = KSTAGE_BYTES / (int)sizeof(T);
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FM = WTM / 16, FN = WTN / 16;      // an M fragment = 16 consecutive x of one tile row
+    constexpr int B_ROWS_PER_PASS = NTHREADS / 8;
+    constexpr int B_PASSES = (BN + B_ROWS_PER_PASS - 1) / B_ROWS_PER_PASS;
+    constexpr int CPAD = 4;
+    static_assert(WM * WN == 4 && sizeof(T) == 2, "4 waves, 16-bit storage");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sH = smem;                                   // [HALO_PIX][144 B]
+    unsigned char* sB = smem + HALO_PIX * HPIX_STRIDE;          // [2][BN][128 B]
+
+    const Gather& g = p.g;
+    const int mode = src_mode<SRC>(g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.ldy + BN - 1) / BN, tiles_x = (g.OW + HT_W - 1) / HT_W, tiles_y = (g.OH + HT_H - 1) / HT_H;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+    const int img = tile_m / (tiles_x * tiles_y), trem = tile_m - img * (tiles_x * tiles_y);
+    const int oy0 = (trem / tiles_x) * HT_H, ox0 = (trem % tiles_x) * HT_W;
+    const int n0 = tile_n * BN;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(g.x0, (long)g.Bn * g.H0 * g.W0 * g.C0 * (long)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1 ? g.x1 : g.x0, g.x1 ? (long)g.Bn * g.IH * g.IW * g.C1 * (long)sizeof(T) : 0);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (long)p.Cout * g.Ktot * (long)sizeof(T));
+
+    // ---- halo side: this thread stages 16-byte chunk (tid & 7) of halo pixels (tid >> 3) + 32 j, j < HALO_PASSES
+    const int hc = tid & 7;
+    unsigned hp0[HALO_PASSES], hp1[HALO_PASSES];
+#pragma unroll
+    for (int j = 0; j < HALO_PASSES; ++j) {
+        const int hp = (tid >> 3) + 32 * j;
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        halo_pix<T, SRC>(g, hp < HALO_PIX, img, oy0 - g.pad + hy, ox0 - g.pad + hx, hp0[j], hp1[j]);
+    }
+    const int ncb = (g.Cin + BK - 1) / BK;          // 64-channel blocks
+    const int nst = ncb * 9;                        // pipeline stages: (channel block, tap)
+    uint4 rh[HALO_PASSES];
+    auto load_halo = [&](int cb) {
+        const int ci = cb * BK + hc * V;
+#pragma unroll
+        for (int j = 0; j < HALO_PASSES; ++j) {
+            unsigned o0, o1 = kOOB;
+            if (mode == SDE_SRC_UPCAT) {
+                o0 = (ci < g.C0 && hp0[j] != kOOB) ? hp0[j] + (unsigned)ci * (unsigned)sizeof(T) : kOOB;
+                o1 = (ci >= g.C0 && ci < g.Cin && hp1[j] != kOOB) ? hp1[j] + (unsigned)(ci - g.C0) * (unsigned)sizeof(T) : kOOB;
+            } else {
+                o0 = (ci < g.Cin && hp0[j] != kOOB) ? hp0[j] + (unsigned)ci * (unsigned)sizeof(T) : kOOB;
+            }
+            uint4 v = buf_load16(rs0, o0);
+            if (mode == SDE_SRC_UPCAT) {
+                const uint4 u = buf_load16(rs1, o1);
+                v.x |= u.x; v.y |= u.y; v.z |= u.z; v.w |= u.w;
+            }
+            rh[j] = v;
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < HALO_PASSES; ++j) {
+            const int hp = (tid >> 3) + 32 * j;
+            if (hp < HALO_PIX) *reinterpret_cast<uint4*>(sH + hp * HPIX_STRIDE + hc * 16) = rh[j];
+        }
+    };
+    // ---- weight side: rows r0 + 32 i, chunk cc (as igemm_kernel); stage s = cb * 9 + tap reads k = tap*Cin + cb*64 + cc*8
+    const int cc = tid & 7, r0 = tid >> 3;
+    uint4 rb[3][B_PASSES];
+    auto load_b = [&](int s, auto SET) {
+        constexpr int st = decltype(SET)::value;
+        const int cb = s / 9, tap = s - cb * 9;
+        const int ci = cb * BK + cc * V;
+        const int k = tap * g.Cin + ci;
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int row = r0 + i * B_ROWS_PER_PASS, n = n0 + row;
+            rb[st][i] = buf_load16(rsw, (ci < g.Cin && row < BN && n < p.Cout) ? (unsigned)(n * g.Ktot + k) * (unsigned)sizeof(T) : kOOB);
+        }
+    };
+    auto store_b = [&](int buf, auto SET) {
+        constexpr int st = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int row = r0 + i * B_ROWS_PER_PASS;
+            if (row < BN) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = rb[st][i];
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int abase[FM];                       // LDS byte offset of this lane's pixel (tile row wm*FM+i, column fr), channel chunk fg, tap (0,0)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) abase[i] = ((wm * FM + i) * HALO_W + fr) * HPIX_STRIDE + fg * 16;
+    auto compute_stage = [&](int buf, int tap) {
+        const int toff = ((tap / 3) * HALO_W + (tap % 3)) * HPIX_STRIDE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const uint4*>(sH + abase[i] + toff + kk * 64);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wn * WTN + j * 16 + fr;
+                b[j] = *reinterpret_cast<const uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + (((kk * 4 + fg) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = mma64<T>(a[i], b[j], acc[i][j]);
+        }
+    };
+    // one step: request weights of stage st+3, (at the first tap of a block) request the NEXT block's halo into registers,
+    // multiply stage st, publish weights of stage st+1; at a block boundary swap the halo tile (all waves are past their reads).
+    auto step = [&](int st, auto CUR, auto NXT) {
+        if (st >= nst) return;
+        const int cb = st / 9, tap = st - cb * 9;
+        if (st + 3 < nst) load_b(st + 3, CUR);
+        if (tap == 0 && cb + 1 < ncb) load_halo(cb + 1);
+        compute_stage(st & 1, tap);
+        if (st + 1 < nst) store_b((st + 1) & 1, NXT);
+        __syncthreads();
+        if (tap == 8 && cb + 1 < ncb) {
+            store_halo();
+            __syncthreads();
+        }
+    };
+    load_halo(0);
+    load_b(0, IC<0>{});
+    if (nst > 1) load_b(1, IC<1>{});
+    if (nst > 2) load_b(2, IC<2>{});
+    store_halo();
+    store_b(0, IC<0>{});
+    __syncthreads();
+    for (int s = 0; s < nst; s += 3) {
+        step(s, IC<0>{}, IC<1>{});
+        step(s + 1, IC<1>{}, IC<2>{});
+        step(s + 2, IC<2>{}, IC<0>{});
+    }
+
+    // ---- epilogue (as igemm_kernel; tile row r = ty*16 + tx -> output pixel (oy0+ty, ox0+tx))
+    float* sC = reinterpret_cast<float*>(smem);   // [BM][BN + CPAD]
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * WTM + i * 16 + fg * 4 + r, col = wn * WTN + j * 16 + fr;
+                sC[row * (BN + CPAD) + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr int G4 = BN / 4;
+    const bool vec_ok = (p.ldy % 4) == 0;
+    for (int id = tid; id < BM * G4; id += NTHREADS) {
+        const int row = id / G4, c0 = (id - row * G4) * 4;
+        const int oy = oy0 + row / HT_W, ox = ox0 + row % HT_W, n = n0 + c0;
+        const bool rok = oy < g.OH && ox < g.OW;
+        if (!rok || n >= p.ldy) {
+            if (p.stats && !rok) *reinterpret_cast<float4*>(&sC[row * (BN + CPAD) + c0]) = make_float4(0.f, 0.f, 0.f, 0.f);   // not part of the statistics
+            continue;
+        }
+        const float4 q = *reinterpret_cast<const float4*>(&sC[row * (BN + CPAD) + c0]);
+        float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = v[e];
+            if (p.bias && n + e < p.Cout) t += p.bias[n + e];
+            if (p.act == SDE_ACT_ELU) t = t > 0.f ? t : expm1f(t);
+            if (n + e >= p.Cout) t = 0.f;
+            v[e] = t;
+        }
+        T* dst = (T*)p.y + ((size_t)(img * g.OH + oy) * g.OW + ox) * p.ldy + n;
+        T o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = from_f32<T>(v[e]);
+        if (vec_ok && n + 4 <= p.ldy) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(o);
+        else for (int e = 0; e < 4 && n + e < p.ldy; ++e) dst[e] = o[e];
+        if (p.stats)
+            *reinterpret_cast<float4*>(&sC[row * (BN + CPAD) + c0]) = make_float4(to_f32<T>(o[0]), to_f32<T>(o[1]), to_f32<T>(o[2]), to_f32<T>(o[3]));
+    }
+    if (p.stats) {
+        __syncthreads();
+        constexpr int PARTS = NTHREADS / BN >= 1 ? NTHREADS / BN : 1;
+        float* red = sC + BM * (BN + CPAD);
+        const int c = tid % BN, part = tid / BN;
+        float s1 = 0.f, s2 = 0.f;
+        if (part < PARTS)     // rows outside the image were zeroed above, so they add nothing
+            for (int r = part; r < BM; r += PARTS) { const float t = sC[r * (BN + CPAD) + c]; s1 += t; s2 += t * t; }
+        if (part < PARTS) { red[(part * BN + c) * 2] = s1; red[(part * BN + c) * 2 + 1] = s2; }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Cout) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) { a += red[(q * BN + tid) * 2]; b += red[(q * BN + tid) * 2 + 1]; }
+            p.stats[((size_t)tile_m * p.Cout + n0 + tid) * 2 + 0] = a;
+            p.stats[((size_t)tile_m * p.Cout + n0 + tid) * 2 + 1] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Weight gradient:  dW[Cout, K] = sum_m dY[m, Cout]^T * im2col(X)[m, K], split over pixel ranges into fp32 slabs
 // ------------------------------------------------------------------------------------------------------------------
 struct WGradP {
@@ -804,6 +1036,50 @@ int dispatch_src(const IGemmP& p, hipStream_t s) {
     }
 }
 
+// ---- LDS-halo 3x3 kernel: when it applies and how it tiles (one place; sde_conv_fwd_tiles_m / _variant use it too)
+int g_halo_min_blocks = 192;      // below this many workgroups the 64x64 generic tiles fill the chip better (sde_conv_set_halo_min_blocks)
+
+bool use_halo(const Gather& g, int dtype, int ldy) {
+    static const int off = [] { const char* e = getenv("SDE_NO_HALO"); return e ? atoi(e) : 0; }();
+    if (off || g_halo_min_blocks < 0 || dtype != SDE_BF16 || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.mode == SDE_SRC_ZEROINS) return false;
+    if (g.mode == SDE_SRC_UPCAT && !g.reflect) return false;
+    if (g.Cin % 8 || g.OH < HT_H || g.OW < HT_W) return false;
+    const long tiles = (long)sde_cdiv(g.OH, HT_H) * sde_cdiv(g.OW, HT_W);
+    if ((double)g.OH * g.OW < 0.8 * (double)tiles * HT_H * HT_W) return false;          // ragged tiling: the generic kernel wastes less
+    if (tiles * g.Bn * sde_cdiv(ldy, 128) < g_halo_min_blocks) return false;             // too few workgroups: prefer the 64x64 generic tiles
+    return true;
+}
+int halo_tiles_m(const Gather& g) { return g.Bn * sde_cdiv(g.OH, HT_H) * sde_cdiv(g.OW, HT_W); }
+
+template <typename T, int BN, int WM, int WN, int SRC>
+int launch_halo(const IGemmP& p, hipStream_t s) {
+    constexpr int stage = HALO_PIX * HPIX_STRIDE + 2 * BN * KSTAGE_BYTES;
+    constexpr int ctile = 128 * (BN + 4) * 4 + NTHREADS * 2 * 4;
+    constexpr int lds = stage > ctile ? stage : ctile;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&halo3_kernel<T, BN, WM, WN, SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    dim3 grid(halo_tiles_m(p.g) * sde_cdiv(p.ldy, BN));
+    hipLaunchKernelGGL((halo3_kernel<T, BN, WM, WN, SRC>), grid, dim3(NTHREADS), lds, s, p);
+    return 0;
+}
+template <int BN, int WM, int WN>
+int dispatch_halo_src(const IGemmP& p, hipStream_t s) {
+    if (p.g.mode == SDE_SRC_UPCAT) return launch_halo<bf16_t, BN, WM, WN, SRC_UPCAT_REFLECT>(p, s);
+    return p.g.reflect ? launch_halo<bf16_t, BN, WM, WN, SRC_PLAIN_REFLECT>(p, s) : launch_halo<bf16_t, BN, WM, WN, SRC_PLAIN_ZERO>(p, s);
+}
+int halo_bn(int ldy) { return ldy > 64 ? 128 : (ldy > 32 ? 64 : (ldy > 16 ? 32 : 16)); }
+int dispatch_halo(const IGemmP& p, hipStream_t s) {
+    switch (halo_bn(p.ldy)) {
+        case 128: return dispatch_halo_src<128, 2, 2>(p, s);
+        case 64: return dispatch_halo_src<64, 2, 2>(p, s);
+        case 32: return dispatch_halo_src<32, 4, 1>(p, s);
+        default: return dispatch_halo_src<16, 4, 1>(p, s);
+    }
+}
+
 template <typename T>
 int dispatch_igemm(const IGemmP& p, hipStream_t s) {
     switch (pick_tile(p.g.M, p.ldy)) {
@@ -893,16 +1169,25 @@ int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias
     SDE_CHECK_ARG(act == SDE_ACT_NONE || act == SDE_ACT_ELU, "sde_conv_fwd: bad act %d", act);
     (void)V;
     p.w = w_packed; p.bias = bias; p.y = y; p.stats = stats; p.Cout = Cout; p.ldy = ldy; p.act = act;
-    if (d->dtype == SDE_BF16) dispatch_igemm<bf16_t>(p, (hipStream_t)stream);
+    if (use_halo(p.g, d->dtype, ldy)) dispatch_halo(p, (hipStream_t)stream);
+    else if (d->dtype == SDE_BF16) dispatch_igemm<bf16_t>(p, (hipStream_t)stream);
     else dispatch_igemm<float>(p, (hipStream_t)stream);
     SDE_CHECK_LAUNCH("sde_conv_fwd");
     return SDE_OK;
 }
 
-int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) { return pick_tile((long)d->Bn * d->OH * d->OW, ldy); }
+static int gather_of(const sde_conv_desc* d, Gather& g) { return fill_gather(d, g, "sde_conv_fwd_tiles_m"); }
+
+int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
+    Gather g;
+    if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return 3128000 + halo_bn(ldy);      // 3128<BN>: LDS-halo 3x3 kernel
+    return pick_tile((long)d->Bn * d->OH * d->OW, ldy);
+}
 
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
     // number of M tiles the dispatcher will use (= rows of the BN-statistics slab)
+    Gather g;
+    if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return halo_tiles_m(g);
     const long M = (long)d->Bn * d->OH * d->OW;
     return sde_cdiv(M, pick_tile(M, ldy) / 1000);
 }
@@ -979,6 +1264,12 @@ int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int
     }
     SDE_CHECK_LAUNCH("sde_pack_weight");
     return SDE_OK;
+}
+
+int sde_conv_set_halo_min_blocks(int min_blocks) {
+    const int old = g_halo_min_blocks;
+    g_halo_min_blocks = min_blocks;
+    return old;
 }
 
 int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total, int dtype, sde_stream_t stream) {

@@ -28,6 +28,7 @@ L.register_protos({
     "sde_conv_fwd": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P], c_int),
     "sde_conv_fwd_tiles_m": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_fwd_variant": ([POINTER(ConvDesc), _I], c_int),
+    "sde_conv_set_halo_min_blocks": ([_I], c_int),
     "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_wgrad": ([POINTER(ConvDesc), _P, _I, _I, _I, _P, _I, _P, _I, _P], c_int),
     "sde_prep_input": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], c_int),

@@ -301,3 +301,94 @@ def test_full_size_conv_properties(NN):
     assert relerr(y12.cpu(), (y1 + y2).cpu()) < 2e-2
     ref = F.conv2d(x1[:2].float().permute(0, 3, 1, 2).cpu(), w.cpu(), None, 1, 1)
     check(nchw(y1[:2].to(torch.bfloat16), C), ref, torch.bfloat16, "sub-sample vs fp32 cpu")
+
+
+HALO_CASES = [
+    # name, B, H, W, Cin, Cout, reflect, bias, act
+    ("halo_64_64_zero", 2, 16, 32, 64, 64, False, False, 0),
+    ("halo_128_128_zero", 2, 16, 32, 128, 128, False, False, 0),
+    ("halo_96_32_refl_elu", 2, 24, 48, 96, 32, True, True, 1),        # channel tail inside the second 64-channel block
+    ("halo_16_16_refl_elu", 2, 24, 48, 16, 16, True, True, 1),
+    ("halo_32_1_refl_head", 2, 16, 32, 32, 1, True, True, 0),
+    ("halo_ragged_64_64", 2, 20, 44, 64, 64, False, True, 0),         # 20x44 is not a multiple of the 8x16 tile
+    ("halo_256_256_zero", 1, 16, 32, 256, 256, False, False, 0),      # 4 channel blocks, 2 N tiles
+]
+
+
+@pytest.fixture
+def force_halo(NN):
+    from simpledepthestimation_amd.hip import lib as L
+    old = L.lib().sde_conv_set_halo_min_blocks(0)
+    yield
+    L.lib().sde_conv_set_halo_min_blocks(old)
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
+def test_conv_halo_kernel(NN, force_halo, case):
+    """The LDS-halo 3x3 kernel (forward and data-gradient, incl. the padded 'full' gradient of reflection layers) vs fp32 CPU."""
+    name, B, H, W, Cin, Cout, reflect, has_bias, act = case
+    dtype, V = torch.bfloat16, 8
+    g = torch.Generator().manual_seed(len(name) * 7)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).bfloat16().float()
+    b = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    xin = F.pad(xr, (1, 1, 1, 1), mode="reflect") if reflect else xr
+    yr = F.conv2d(xin, wr, br, 1, 0 if reflect else 1)
+    if act == 1:
+        yr = F.elu(yr)
+    gy = torch.randn(yr.shape, generator=g).bfloat16().float()
+    yr.backward(gy)
+    xd = nhwc(x, dtype, V).requires_grad_(True)
+    wd = w.clone().to(dev).requires_grad_(True)
+    bd = b.clone().to(dev).requires_grad_(True) if has_bias else None
+    y = NN.conv2d(xd, wd, bd, stride=1, pad=1, reflect=reflect, act=act)
+    check(nchw(y, Cout), yr.detach(), dtype, "y")
+    if y.shape[3] > Cout:
+        assert (y[..., Cout:] == 0).all()
+    y.backward(nhwc(gy, dtype, V))
+    check(nchw(xd.grad, Cin), xr.grad, dtype, "dX")
+    check(wd.grad.cpu(), wr.grad, dtype, "dW")
+
+
+@pytest.mark.parametrize("C0,C1,Cout", [(32, 64, 32), (16, 0, 16), (64, 256, 64)])
+def test_conv_halo_upsample_concat(NN, force_halo, C0, C1, Cout):
+    dtype, V = torch.bfloat16, 8
+    g = torch.Generator().manual_seed(C0 * 3 + C1)
+    B, h, w = 2, 8, 16
+    x0 = torch.randn(B, C0, h, w, generator=g).bfloat16().float()
+    x1 = torch.randn(B, C1, 2 * h, 2 * w, generator=g).bfloat16().float() if C1 else None
+    wt = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) / math.sqrt((C0 + C1) * 9)).bfloat16().float()
+    bs = torch.randn(Cout, generator=g) * 0.1
+    x0r = x0.clone().requires_grad_(True); x1r = x1.clone().requires_grad_(True) if C1 else None
+    wr = wt.clone().requires_grad_(True)
+    up = F.interpolate(x0r, scale_factor=2, mode="nearest")
+    cat = torch.cat([up, x1r], 1) if C1 else up
+    yr = F.elu(F.conv2d(F.pad(cat, (1, 1, 1, 1), mode="reflect"), wr, bs))
+    gy = torch.randn(yr.shape, generator=g).bfloat16().float()
+    yr.backward(gy)
+    x0d = nhwc(x0, dtype, V).requires_grad_(True)
+    x1d = nhwc(x1, dtype, V).requires_grad_(True) if C1 else None
+    wd = wt.clone().to(dev).requires_grad_(True)
+    y = NN.conv2d(x0d, wd, bs.to(dev), stride=1, pad=1, reflect=True, act=1, skip=x1d, upsample=True)
+    check(nchw(y, Cout), yr.detach(), dtype, "y")
+    y.backward(nhwc(gy, dtype, V))
+    check(nchw(x0d.grad, C0), x0r.grad, dtype, "dx0")
+    if C1:
+        check(nchw(x1d.grad, C1), x1r.grad, dtype, "dx1")
+
+
+def test_conv_halo_batchnorm_stats(NN, force_halo):
+    """BatchNorm statistics produced by the halo kernel's epilogue (ragged tiles must not pollute them)."""
+    g = torch.Generator().manual_seed(9)
+    B, H, W, Cin, C = 2, 20, 44, 32, 64
+    x = (torch.randn(B, Cin, H, W, generator=g) + 0.3).bfloat16().float()
+    w = (torch.randn(C, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).bfloat16().float()
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.2
+    yc = F.conv2d(x, w, None, 1, 1)
+    yc = yc.bfloat16().float()
+    o = F.relu(F.batch_norm(yc, torch.zeros(C), torch.ones(C), gamma, beta, True, 0.1, 1e-5))
+    y, stats = NN.conv2d(nhwc(x, torch.bfloat16, 8), w.to(dev), None, stride=1, pad=1, bn_stats=True)
+    out = NN.batch_norm_act(y, stats, gamma.to(dev), beta.to(dev), torch.zeros(C, device=dev), torch.ones(C, device=dev))
+    check(nchw(out, C), o, torch.bfloat16, "bn(halo conv)")
