@@ -1039,17 +1039,25 @@ int dispatch_src(const IGemmP& p, hipStream_t s) {
 // ---- LDS-halo 3x3 kernel: when it applies and how it tiles (one place; sde_conv_fwd_tiles_m / _variant use it too)
 int g_halo_min_blocks = 192;      // below this many workgroups the 64x64 generic tiles fill the chip better (sde_conv_set_halo_min_blocks)
 
+long halo_tiles(const Gather& g) { return (long)g.Bn * sde_cdiv(g.OH, HT_H) * sde_cdiv(g.OW, HT_W); }
+// N tile of the halo kernel: 128 wide when that still gives >= 256 workgroups, else 64 (mid-resolution layers), 32 / 16 for narrow outputs
+int halo_bn(const Gather& g, int ldy) {
+    if (ldy > 64) return halo_tiles(g) * sde_cdiv(ldy, 128) >= 256 ? 128 : 64;
+    return ldy > 32 ? 64 : (ldy > 16 ? 32 : 16);
+}
 bool use_halo(const Gather& g, int dtype, int ldy) {
     static const int off = [] { const char* e = getenv("SDE_NO_HALO"); return e ? atoi(e) : 0; }();
-    if (off || g_halo_min_blocks < 0 || dtype != SDE_BF16 || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.mode == SDE_SRC_ZEROINS) return false;
+    static const int min_n = [] { const char* e = getenv("SDE_HALO_MIN_N"); return e ? atoi(e) : 0; }();
+    if (off || ldy < min_n || g_halo_min_blocks < 0 || dtype != SDE_BF16 || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.mode == SDE_SRC_ZEROINS) return false;
     if (g.mode == SDE_SRC_UPCAT && !g.reflect) return false;
     if (g.Cin % 8 || g.OH < HT_H || g.OW < HT_W) return false;
+    if (sde_cdiv(g.Cin, 64) * 64 * 3 > g.Cin * 4) return false;     // the tile stages 64-channel blocks: narrow inputs (Cin < 48) waste MFMA and LDS
     const long tiles = (long)sde_cdiv(g.OH, HT_H) * sde_cdiv(g.OW, HT_W);
-    if ((double)g.OH * g.OW < 0.8 * (double)tiles * HT_H * HT_W) return false;          // ragged tiling: the generic kernel wastes less
-    if (tiles * g.Bn * sde_cdiv(ldy, 128) < g_halo_min_blocks) return false;             // too few workgroups: prefer the 64x64 generic tiles
+    if ((double)g.OH * g.OW < 0.75 * (double)tiles * HT_H * HT_W) return false;         // ragged tiling: the generic kernel wastes less
+    if (halo_tiles(g) * sde_cdiv(ldy, halo_bn(g, ldy)) < g_halo_min_blocks) return false; // too few workgroups: prefer the 64x64 generic tiles
     return true;
 }
-int halo_tiles_m(const Gather& g) { return g.Bn * sde_cdiv(g.OH, HT_H) * sde_cdiv(g.OW, HT_W); }
+int halo_tiles_m(const Gather& g) { return (int)halo_tiles(g); }
 
 template <typename T, int BN, int WM, int WN, int SRC>
 int launch_halo(const IGemmP& p, hipStream_t s) {
@@ -1070,9 +1078,8 @@ int dispatch_halo_src(const IGemmP& p, hipStream_t s) {
     if (p.g.mode == SDE_SRC_UPCAT) return launch_halo<bf16_t, BN, WM, WN, SRC_UPCAT_REFLECT>(p, s);
     return p.g.reflect ? launch_halo<bf16_t, BN, WM, WN, SRC_PLAIN_REFLECT>(p, s) : launch_halo<bf16_t, BN, WM, WN, SRC_PLAIN_ZERO>(p, s);
 }
-int halo_bn(int ldy) { return ldy > 64 ? 128 : (ldy > 32 ? 64 : (ldy > 16 ? 32 : 16)); }
 int dispatch_halo(const IGemmP& p, hipStream_t s) {
-    switch (halo_bn(p.ldy)) {
+    switch (halo_bn(p.g, p.ldy)) {
         case 128: return dispatch_halo_src<128, 2, 2>(p, s);
         case 64: return dispatch_halo_src<64, 2, 2>(p, s);
         case 32: return dispatch_halo_src<32, 4, 1>(p, s);
@@ -1180,7 +1187,7 @@ static int gather_of(const sde_conv_desc* d, Gather& g) { return fill_gather(d, 
 
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
     Gather g;
-    if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return 3128000 + halo_bn(ldy);      // 3128<BN>: LDS-halo 3x3 kernel
+    if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return 3128000 + halo_bn(g, ldy);      // 3128<BN>: LDS-halo 3x3 kernel
     return pick_tile((long)d->Bn * d->OH * d->OW, ldy);
 }
 
