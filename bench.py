@@ -71,11 +71,15 @@ def build(args, device):
 def roofline_pass(trainer, batch, steps, dtype):
     """Event-instrumented eager steps of the same workload: per GEMM launch (kind, tile variant) duration and algorithmic FLOPs."""
     from simpledepthestimation_amd.hip import lib as L
-    trainer._fwd_bwd(batch)                      # eager warm-up (the timed region may have run under graph replay)
+    def one():
+        trainer._fwd_bwd(batch)
+        if trainer._cut is not None:
+            trainer._backward_rest()
+    one()                                        # eager warm-up (the timed region may have run under graph replay)
     torch.cuda.synchronize()
     L.PROFILE = []
     for _ in range(steps):
-        trainer._fwd_bwd(batch)
+        one()
     torch.cuda.synchronize()
     recs, L.PROFILE = L.PROFILE, None
     fam = {}
@@ -97,7 +101,7 @@ def roofline_pass(trainer, batch, steps, dtype):
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     tot_ms = sum(f["ms"] for f in fam.values()); tot_fl = sum(f["flops"] for f in fam.values())
     if dom_key[0] != "igemm":
-        name = "wgrad_kernel+wgrad_reduce_kernel"
+        name = "wgrad_kernel(+slab_fold_kernel)"
     elif dom_key[1] >= 3000000:
         name = f"halo3_kernel<{dtype},8x16 pixels x {dom_key[1] % 1000}>"
     else:

@@ -162,6 +162,18 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout);
 int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, int Cin_real, float* slab, int splits, float* dw, int accumulate,
                    sde_stream_t stream);
 
+/* Deferred form for training loops: sde_conv_wgrad_partial runs the GEMM (+ fold) only and reports where the slabs to sum are;
+ * sde_wgrad_reduce_batched then finishes MANY layers in one launch (items: DEVICE array; `end` = exclusive prefix sum of Cout). */
+int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, const float** reduce_src,
+                           int* reduce_rows, sde_stream_t stream);
+typedef struct sde_wreduce_item {
+    const float* slab; /* reduce_src of sde_conv_wgrad_partial */
+    float* dw;         /* master OIHW fp32 gradient [Cout,Cin_real,KH,KW] */
+    int32_t rows, Cout, KHW, Cin_pad, Cin_real, accumulate;
+    int64_t end;
+} sde_wreduce_item;
+int sde_wgrad_reduce_batched(const sde_wreduce_item* items_dev, int n, long total_blocks, int max_k, sde_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Layers around the convolutions (NHWC, `dtype` storage, fp32 math)
  * ------------------------------------------------------------------------------------------------- */

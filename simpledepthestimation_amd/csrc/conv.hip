@@ -924,6 +924,41 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// The same for many layers in ONE launch: block b finds its (layer, output channel) by binary search in the prefix sums of
+// the layers' Cout.  Used by the training engine, which defers every layer's final slab reduction to the end of a backward phase.
+__global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const sde_wreduce_item* __restrict__ items, int n) {
+    extern __shared__ float sk[];
+    int lo = 0, hi = n - 1;
+    const long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (items[mid].end > b) hi = mid; else lo = mid + 1;
+    }
+    const sde_wreduce_item it = items[lo];
+    const int co = (int)(b - (lo ? items[lo - 1].end : 0));
+    const int K = it.KHW * it.Cin_pad;
+    const size_t total = (size_t)it.Cout * K;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float* src = it.slab + (size_t)co * K + k;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = 0;
+        for (; sp + 3 < it.rows; sp += 4) {
+            s0 += src[(size_t)sp * total]; s1 += src[(size_t)(sp + 1) * total];
+            s2 += src[(size_t)(sp + 2) * total]; s3 += src[(size_t)(sp + 3) * total];
+        }
+        for (; sp < it.rows; ++sp) s0 += src[(size_t)sp * total];
+        sk[k] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    const int nn = it.Cin_real * it.KHW;
+    float* o = it.dw + (size_t)co * nn;
+    for (int j = threadIdx.x; j < nn; j += 256) {
+        const int ci = j / it.KHW, tap = j - ci * it.KHW;
+        const float v = sk[tap * it.Cin_pad + ci];
+        o[j] = it.accumulate ? o[j] + v : v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Weight packing (master fp32 OIHW -> K-major operands)
 // ------------------------------------------------------------------------------------------------------------------
@@ -1213,44 +1248,76 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     return (int)want;
 }
 
-int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, int Cin_real, float* slab, int splits, float* dw,
-                   int accumulate, sde_stream_t stream) {
-    SDE_CHECK_ARG(d && dy && slab && dw, "sde_conv_wgrad: null pointer");
+// GEMM + (for tall slab stacks) fold.  On return *red_src / *red_rows say where the <= SDE_WGRAD_FOLD_ROWS (or `splits`) slabs to sum are.
+static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, hipStream_t s, Gather& g,
+                         const float** red_src, int* red_rows) {
     WGradP p;
     int rc = fill_gather(d, p.g, "sde_conv_wgrad");
     if (rc) return rc;
     const int V = d->dtype == SDE_BF16 ? 8 : 4;
     SDE_CHECK_ARG(Cout > 0 && ldd >= Cout && ldd % V == 0, "sde_conv_wgrad: bad Cout=%d ldd=%d", Cout, ldd);
-    SDE_CHECK_ARG(splits >= 1 && Cin_real >= 1 && Cin_real <= p.g.Cin, "sde_conv_wgrad: bad splits=%d Cin_real=%d", splits, Cin_real);
+    SDE_CHECK_ARG(splits >= 1, "sde_conv_wgrad: bad splits=%d", splits);
     const int BR = d->dtype == SDE_BF16 ? 64 : 32;
     int rps = sde_cdiv(p.g.M, splits);
     rps = sde_cdiv(rps, BR) * BR;
     SDE_CHECK_ARG((long)rps * splits >= p.g.M, "sde_conv_wgrad: split arithmetic");
     p.dy = dy; p.slab = slab; p.Cout = Cout; p.ldd = ldd; p.rows_per_split = rps;
-    hipStream_t s = (hipStream_t)stream;
     if (d->dtype == SDE_BF16) dispatch_wgrad<bf16_t>(p, splits, s);
     else dispatch_wgrad<float>(p, splits, s);
     SDE_CHECK_LAUNCH("sde_conv_wgrad");
-    const size_t lds_red = (size_t)p.g.Ktot * sizeof(float);
-    SDE_CHECK_ARG(lds_red <= 160 * 1024, "sde_conv_wgrad: K=%d too large for the reduce kernel's LDS transpose", p.g.Ktot);
-    static bool red_attr = false;
-    if (!red_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        red_attr = true;
-    }
-    const float* red_src = slab;
-    int red_rows = splits;
+    SDE_CHECK_ARG((size_t)p.g.Ktot * sizeof(float) <= 160 * 1024, "sde_conv_wgrad: K=%d too large for the reduce kernel's LDS transpose", p.g.Ktot);
+    *red_src = slab; *red_rows = splits;
     if (splits > SDE_WGRAD_FOLD_ROWS) {     // fold into the SDE_WGRAD_FOLD_ROWS scratch rows behind the slab stack
         const size_t width4 = (size_t)Cout * p.g.Ktot / 4;      // Ktot is a multiple of 4 elements
         const int chunk = sde_cdiv(splits, SDE_WGRAD_FOLD_ROWS);
-        red_rows = sde_cdiv(splits, chunk);
+        *red_rows = sde_cdiv(splits, chunk);
         float* scratch = slab + (size_t)splits * Cout * p.g.Ktot;
-        hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((width4 + 255) / 256), red_rows), dim3(256), 0, s, slab, splits, width4, chunk, scratch);
+        hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((width4 + 255) / 256), *red_rows), dim3(256), 0, s, slab, splits, width4, chunk, scratch);
         SDE_CHECK_LAUNCH("sde_conv_wgrad/fold");
-        red_src = scratch;
+        *red_src = scratch;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), lds_red, s, red_src, red_rows, Cout, d->KH * d->KW, p.g.Cin, Cin_real, dw, accumulate);
+    g = p.g;
+    return SDE_OK;
+}
+
+static void set_reduce_lds_attr() {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+}
+
+int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, int Cin_real, float* slab, int splits, float* dw,
+                   int accumulate, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && dy && slab && dw, "sde_conv_wgrad: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    Gather g;
+    const float* red_src; int red_rows;
+    int rc = wgrad_partial(d, dy, Cout, ldd, slab, splits, s, g, &red_src, &red_rows);
+    if (rc) return rc;
+    SDE_CHECK_ARG(Cin_real >= 1 && Cin_real <= g.Cin, "sde_conv_wgrad: bad Cin_real=%d", Cin_real);
+    set_reduce_lds_attr();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), (size_t)g.Ktot * sizeof(float), s, red_src, red_rows, Cout, d->KH * d->KW, g.Cin, Cin_real, dw,
+                       accumulate);
     SDE_CHECK_LAUNCH("sde_conv_wgrad/reduce");
+    return SDE_OK;
+}
+
+int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, const float** reduce_src,
+                           int* reduce_rows, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && dy && slab && reduce_src && reduce_rows, "sde_conv_wgrad_partial: null pointer");
+    Gather g;
+    return wgrad_partial(d, dy, Cout, ldd, slab, splits, (hipStream_t)stream, g, reduce_src, reduce_rows);
+}
+
+int sde_wgrad_reduce_batched(const sde_wreduce_item* items_dev, int n, long total_blocks, int max_k, sde_stream_t stream) {
+    SDE_CHECK_ARG(items_dev && n > 0 && total_blocks > 0 && max_k > 0, "sde_wgrad_reduce_batched: bad argument");
+    SDE_CHECK_ARG((size_t)max_k * sizeof(float) <= 160 * 1024, "sde_wgrad_reduce_batched: K=%d too large", max_k);
+    set_reduce_lds_attr();
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(256), (size_t)max_k * sizeof(float), (hipStream_t)stream, items_dev, n);
+    SDE_CHECK_LAUNCH("sde_wgrad_reduce_batched");
     return SDE_OK;
 }
 

@@ -116,6 +116,7 @@ class HipTrainer:
         self._static_out = None
         self._packer = None            # built lazily after the first eager step (needs the operand shapes seen in forward)
         self.batch_pack = adam_fn is None
+        self._wreduce = HN.WGradReducer() if adam_fn is None else None      # one weight-gradient slab reduction launch per backward phase
 
     # ------------------------------------------------------------------------------------------------------------
     def set_lr(self, lrs):
@@ -131,13 +132,28 @@ class HipTrainer:
         out = self.model(batch)
         loss_dict = {k: v for k, v in out.items() if "loss" in k}
         losses = sum(loss_dict.values())
-        losses.backward()
+        self._backward(lambda: losses.backward())
         if self._packer is None and self.batch_pack:
             try:
                 self._packer = HN.WeightPacker(self.model)
             except Exception:
                 self.batch_pack = False             # model without HIP convolutions
         return loss_dict
+
+    def _backward(self, run):
+        """One backward phase with the convolutions' weight-gradient reductions deferred to a single launch at its end."""
+        HN.WGRAD_DEFER = self._wreduce
+        try:
+            run()
+            if self._wreduce is not None:
+                self._wreduce.flush()
+        finally:
+            HN.WGRAD_DEFER = None
+            if self._wreduce is not None:
+                self._wreduce.jobs, self._wreduce._seen = [], set()       # nothing left registered if backward raised
+
+    def _backward_rest(self):
+        self._backward(self._cut.backward_rest)
 
     def _allreduce(self, lo=0, hi=None, wait=True):
         """SUM all-reduce of gflat[lo:hi] in buckets; returns the work handles (already waited on unless wait=False)."""
@@ -191,7 +207,7 @@ class HipTrainer:
             for _ in range(warmup):
                 self._fwd_bwd(dict(self._static_batch))
                 if self._cut is not None:
-                    self._cut.backward_rest()
+                    self._backward_rest()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
@@ -200,7 +216,9 @@ class HipTrainer:
         if self._cut is not None:                  # phase B: the rest of backward, same memory pool, replayed after phase A
             self._graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_b, pool=self._graph.pool()):
-                self._cut.backward_rest()
+                self._backward_rest()
+        if self._wreduce is not None:
+            self._wreduce.fill_tables()
         return self
 
     def step(self, batch):
@@ -221,7 +239,7 @@ class HipTrainer:
             if self._graph_b is not None:
                 self._graph_b.replay()
             else:
-                self._cut.backward_rest()
+                self._backward_rest()
             early = self._allreduce(0, self.late_start, wait=False)
             for h in late + early:
                 h.wait()

@@ -31,6 +31,8 @@ L.register_protos({
     "sde_conv_set_halo_min_blocks": ([_I], c_int),
     "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_wgrad": ([POINTER(ConvDesc), _P, _I, _I, _I, _P, _I, _P, _I, _P], c_int),
+    "sde_conv_wgrad_partial": ([POINTER(ConvDesc), _P, _I, _I, _P, _I, POINTER(c_void_p), POINTER(c_int), _P], c_int),
+    "sde_wgrad_reduce_batched": ([_P, _I, ctypes.c_long, _I, _P], c_int),
     "sde_prep_input": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_bn_finalize": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P], c_int),
     "sde_bn_eval_params": ([_P, _P, _P, _P, _F, _I, _P, _P], c_int),
@@ -229,11 +231,19 @@ class _Conv2d(torch.autograd.Function):
             else:
                 import contextlib
                 wctx = contextlib.nullcontext()
+            slab = torch.empty(splits + (FOLD_ROWS if splits > FOLD_ROWS else 0), Cout, KH * KW * (C0 + C1), device=dev)   # + fold scratch rows
+            dw = wslot if wslot is not None else torch.empty_like(weight)
+            defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and WGRAD_DEFER.accepts(wslot)) else None
             with wctx:
-                slab = torch.empty(splits + 16, Cout, KH * KW * (C0 + C1), device=dev)       # + SDE_WGRAD_FOLD_ROWS scratch rows
-                dw = wslot if wslot is not None else torch.empty_like(weight)
-                _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
-                                                                             int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
+                if defer is not None:
+                    src, rows = c_void_p(), c_int()
+                    _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits,
+                                                                                         ctypes.byref(src), ctypes.byref(rows), L.stream()),
+                                                              "sde_conv_wgrad_partial"), meta)
+                    defer.add(slab, src.value, rows.value, wslot, Cout, KH * KW, C0 + C1, Cin)
+                else:
+                    _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
+                                                                                 int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
                 if forked:
                     slab.record_stream(side)
             if wslot is not None:
@@ -263,6 +273,66 @@ class _Conv2d(torch.autograd.Function):
         if forked:
             torch.cuda.current_stream().wait_stream(side)       # join: dz / x0 / x1 stay alive until both GEMMs are done
         return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
+
+
+class WReduceItem(Structure):
+    _fields_ = [("slab", c_void_p), ("dw", c_void_p), ("rows", c_int32), ("Cout", c_int32), ("KHW", c_int32), ("Cin_pad", c_int32),
+                ("Cin_real", c_int32), ("accumulate", c_int32), ("end", ctypes.c_int64)]
+
+
+class WGradReducer:
+    """Defers the final slab reduction of every convolution's weight gradient to ONE launch per backward phase.
+
+    While installed (`WGRAD_DEFER = reducer`, done by HipTrainer around backward) each _Conv2d.backward runs only the GEMM (+fold) and
+    registers its slabs here; flush() sums them all into the flat gradient.  Nothing persists across steps: slabs come from the caching
+    allocator (the graph pool under capture) and are released at flush.  Under hipGraph capture the item table's device memory is
+    reserved during capture and filled right after it (fill_tables()), since its contents are only pointers."""
+
+    def __init__(self):
+        self.jobs, self._seen = [], set()
+        self._tables = []          # (device table, host bytes) kept alive for graph replays
+        self._pending = []
+
+    def accepts(self, wslot):
+        # a weight used twice in one phase (shared modules) must not be accumulated by two blocks of one launch: the second use reduces at once
+        return wslot.data_ptr() not in self._seen
+
+    def add(self, slab, src_ptr, rows, wslot, Cout, KHW, Cin_pad, Cin_real):
+        self._seen.add(wslot.data_ptr())
+        self.jobs.append((slab, wslot, (src_ptr, wslot.data_ptr(), rows, Cout, KHW, Cin_pad, Cin_real, 1)))
+
+    def flush(self):
+        if not self.jobs:
+            return
+        import numpy as np
+        items, end, max_k = [], 0, 0
+        for _, _, it in self.jobs:
+            end += it[3]
+            max_k = max(max_k, it[4] * it[5])
+            items.append(WReduceItem(*it, end))
+        arr = (WReduceItem * len(items))(*items)
+        host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+        dev = self.jobs[0][0].device
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            table = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
+            self._tables.append(table)
+            self._pending.append((table, host))
+        else:
+            table = host.to(dev)
+        _timed("wgrad_reduce", 0.0, 0, lambda: L.check(L.lib().sde_wgrad_reduce_batched(L.ptr(table), len(items), end, max_k, L.stream()),
+                                                       "sde_wgrad_reduce_batched"), dict(jobs=len(items)))
+        self.jobs, self._seen = [], set()
+
+    def fill_tables(self):
+        """After graph capture: write the item tables the captured reduce launches read."""
+        for table, host in self._pending:
+            table.copy_(host)
+        self._pending = []
+
+
+WGRAD_DEFER = None      # HipTrainer installs a WGradReducer around backward
+FOLD_ROWS = 16          # SDE_WGRAD_FOLD_ROWS
 
 
 class PackItem(Structure):

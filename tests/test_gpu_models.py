@@ -213,6 +213,28 @@ def test_two_phase_backward_equals_plain_backward():
     assert res[1][0].abs().sum() > 0
 
 
+@pytest.mark.parametrize("arch", ["SupDepthModel", "MonoDepth2Model"])
+def test_deferred_wgrad_reduce_equals_immediate(arch):
+    """One batched slab-reduction launch per backward phase (WGradReducer) == the per-layer reductions, bit for bit."""
+    from simpledepthestimation_amd.engine import trainer as T
+    sd = OM.init_state_dict(18, with_pose=arch != "SupDepthModel", seed=11)
+    batch = sup_batch(2, 64, 192, 12) if arch == "SupDepthModel" else mono_batch(2, 64, 192, 12)
+    dbatch = {k: ([x.to(dev) for x in v] if isinstance(v, list) else v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    mk = T.supervised_trainer if arch == "SupDepthModel" else T.monodepth2_trainer
+    res = []
+    for deferred in (False, True):
+        model = build(arch, 18, sd).train()
+        tr = mk(model, make_cfg(arch, 18))
+        if not deferred:
+            tr._wreduce = None
+        for _ in range(2):
+            tr.step(clone_batch(dbatch))
+        res.append((tr.gflat.clone(), tr.pflat.clone()))
+    assert torch.equal(res[0][0], res[1][0]), "gradients differ between immediate and deferred weight-gradient reduction"
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[1][0].abs().sum() > 0
+
+
 def test_graph_replay_equals_eager():
     """The captured hipGraph step (zero-grad + batched weight pack + forward + backward) reproduces the eager step bit for bit."""
     from simpledepthestimation_amd.engine.trainer import supervised_trainer
