@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBPS = 8000.0
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}    # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 WORKLOADS = {
     "sup_r50": dict(arch="SupDepthModel", enc="50", desc="Supervised ResNet-50 (BASELINE configs[1])"),
@@ -91,6 +92,22 @@ def roofline_pass(trainer, batch, steps, dtype):
                 m = meta or {}
                 f.write(f"{kind},{variant},{m.get('M')},{m.get('N')},{m.get('K')},{m.get('k')},{m.get('s')},{m.get('mode')},{m.get('splits', '')},"
                         f"{us:.1f},{flops / us / 1e6:.1f},{m.get('bytes', 0) / us / 1e3:.0f}\n")
+    photo = {}
+    for kind, nbytes, variant, e0, e1, meta in recs:
+        if kind.startswith("photo"):
+            f = photo.setdefault((kind, meta["h"], meta["w"]), {"ms": 0.0, "bytes": 0.0, "launches": 0})
+            f["ms"] += e0.elapsed_time(e1); f["bytes"] += nbytes; f["launches"] += 1
+    recs = [r for r in recs if not r[0].startswith("photo")]
+    hbm = None
+    if photo:
+        k0 = max((k for k in photo if k[0] == "photo_fwd"), key=lambda k: k[1] * k[2])        # the full-resolution scale
+        v = photo[k0]
+        gbps = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+        hbm = {"bound": "hbm", "kernel": f"photo_fwd_kernel (warp + SSIM + L1 + min/automask), scale {k0[1]}x{k0[2]}", "achieved": round(gbps, 1),
+               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+               "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
+               "all": {f"{k[0]}:{k[1]}x{k[2]}": {"us": round(x["ms"] * 1e3 / x["launches"], 2), "GBps": round(x["bytes"] / (x["ms"] * 1e-3) / 1e9, 1)}
+                       for k, x in sorted(photo.items(), key=lambda kv: -kv[0][1])}}
     for kind, flops, variant, e0, e1, _meta in recs:
         key = ("igemm" if kind.startswith("igemm") else kind, variant)
         f = fam.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
@@ -106,7 +123,7 @@ def roofline_pass(trainer, batch, steps, dtype):
         name = f"halo3_kernel<{dtype},8x16 pixels x {dom_key[1] % 1000}>"
     else:
         name = f"igemm_kernel<{dtype},{dom_key[1] // 1000}x{dom_key[1] % 1000}>"
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+    return hbm, {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
             "kernel": name, "launches_per_step": dom["launches"] // steps, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
             "gemm_flops_per_step": tot_fl / steps, "gemm_ms_per_step": round(tot_ms / steps, 3),
             "all_gemm_achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
@@ -218,7 +235,9 @@ def main():
                           "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "allreduce_overlap": bool(trainer.overlap)},
                "final_losses": final}
         if args.profile_steps > 0:
-            out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype)
+            hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype)
+            if hbm is not None:
+                out["roofline_photometric"] = hbm        # MonoDepth2 workloads: the HBM-bound warp+SSIM kernel next to the dominant GEMM
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -17,9 +17,11 @@ MI355X-first choices
 """
 import math
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from ..hip import lib as HL
 from ..hip import nn as HN
 
 
@@ -87,7 +89,7 @@ class HipTrainer:
         self.seg_end = torch.tensor(seg_end, dtype=torch.long, device=dev)
         self.seg_lr = torch.tensor([g.lr for g in self.groups], dtype=torch.float32, device=dev)
         self.seg_wd = torch.tensor([g.weight_decay for g in self.groups], dtype=torch.float32, device=dev)
-        self.bias_corr = torch.ones(2, dtype=torch.float32, device=dev)
+        self._ring = None
         self.t = 0
         # ---- gradient buckets for the all-reduce (contiguous slices of the flat gradient)
         per = max(1, int(bucket_mb * (1 << 20) / 4))
@@ -173,9 +175,19 @@ class HipTrainer:
     def _optimizer(self):
         self.t += 1
         b1, b2 = self.betas
-        self.bias_corr.copy_(torch.tensor([1.0 - b1 ** self.t, 1.0 - b2 ** self.t], dtype=torch.float32), non_blocking=True)
-        self._adam_fn(self.pflat, self.gflat, self.m, self.v, self.seg_end, self.seg_lr, self.seg_wd, self.bias_corr, b1, b2, self.eps,
+        bc = np.array([1.0 - b1 ** self.t, 1.0 - b2 ** self.t], dtype=np.float32)
+        slot = None
+        if self.device.type == "cuda":
+            if self._ring is None:
+                self._ring = HL.UploadRing(self.device)
+            slot = self._ring.acquire(8)                       # per-step scalars: pinned, stream-ordered, no buffer rewritten in flight
+            bias_corr = slot.write(bc.view(np.uint8)).view(torch.float32)
+        else:
+            bias_corr = torch.from_numpy(bc)
+        self._adam_fn(self.pflat, self.gflat, self.m, self.v, self.seg_end, self.seg_lr, self.seg_wd, bias_corr, b1, b2, self.eps,
                       1.0 / self.world, self.adamw)
+        if slot is not None:
+            slot.release()
 
     # ------------------------------------------------------------------------------------------------------------
     def _to_static(self, batch):
@@ -187,14 +199,22 @@ class HipTrainer:
             return v
         return {k: conv(v) for k, v in batch.items()}
 
+    def _staged(self, v):
+        """The static batch may still be read by the previous replay: never write pageable host data straight into it.  Pageable
+        tensors first land in a fresh device tensor (blocking copy), the copy into the static buffer is then device-to-device in
+        stream order; pinned and device tensors are already stream-ordered."""
+        if v.device.type == "cpu" and not v.is_pinned():
+            return v.to(self.device)
+        return v
+
     def _copy_into_static(self, batch):
         for k, v in batch.items():
             s = self._static_batch[k]
             if torch.is_tensor(v):
-                s.copy_(v, non_blocking=True)
+                s.copy_(self._staged(v), non_blocking=True)
             elif isinstance(v, list):
                 for a, b in zip(s, v):
-                    a.copy_(b if torch.is_tensor(b) else torch.as_tensor(b), non_blocking=True)
+                    a.copy_(self._staged(b if torch.is_tensor(b) else torch.as_tensor(b)), non_blocking=True)
             elif s != v:
                 raise RuntimeError(f"non-tensor batch entry '{k}' changed ({s} -> {v}); re-capture the graph")
 

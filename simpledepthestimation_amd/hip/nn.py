@@ -4,6 +4,7 @@ Tensor convention: activations are NHWC torch tensors [B, H, W, C] (float32 or b
 parameters stay fp32 in the reference's layouts (conv weight OIHW) so state dicts are interchangeable.
 """
 import ctypes
+import os
 from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_long, c_void_p
 
 import torch
@@ -106,16 +107,7 @@ def _desc(x0, x1, src_mode, KH, KW, stride, pad, reflect, IH, IW, OH, OW):
     return d
 
 
-def _timed(kind, flops, variant, call, meta=None):
-    """Run `call` bracketed by events on the current stream when L.PROFILE is a list (bench.py's roofline pass)."""
-    if L.PROFILE is None:
-        return call()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    r = call()
-    e1.record()
-    L.PROFILE.append((kind, float(flops), variant, e0, e1, meta))
-    return r
+_timed = L.timed
 
 
 def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device, kind="igemm_fwd", flops=0.0):
@@ -285,13 +277,14 @@ class WGradReducer:
 
     While installed (`WGRAD_DEFER = reducer`, done by HipTrainer around backward) each _Conv2d.backward runs only the GEMM (+fold) and
     registers its slabs here; flush() sums them all into the flat gradient.  Nothing persists across steps: slabs come from the caching
-    allocator (the graph pool under capture) and are released at flush.  Under hipGraph capture the item table's device memory is
-    reserved during capture and filled right after it (fill_tables()), since its contents are only pointers."""
+    allocator (the graph pool under capture) and are released at flush; the item table goes through an UploadRing slot (eager) or is
+    reserved during hipGraph capture and filled right after it (fill_tables()), since its contents are only pointers."""
 
     def __init__(self):
         self.jobs, self._seen = [], set()
-        self._tables = []          # (device table, host bytes) kept alive for graph replays
+        self._tables = []          # device tables of captured launches, kept alive for the graph's replays
         self._pending = []
+        self._ring = None
 
     def accepts(self, wslot):
         # a weight used twice in one phase (shared modules) must not be accumulated by two blocks of one launch: the second use reduces at once
@@ -306,22 +299,35 @@ class WGradReducer:
             return
         import numpy as np
         items, end, max_k = [], 0, 0
-        for _, _, it in self.jobs:
-            end += it[3]
-            max_k = max(max_k, it[4] * it[5])
+        for slab, wslot, it in self.jobs:
+            src, dwp, rows, Cout, KHW, Cin_pad, Cin_real, _ = it
+            # host-side operand check: the rows to sum must lie inside the slab tensor, the gradient slot must have the OIHW size
+            lo, hi = slab.data_ptr(), slab.data_ptr() + slab.numel() * 4
+            if not (src is not None and lo <= src and src + rows * Cout * KHW * Cin_pad * 4 <= hi and wslot.numel() == Cout * Cin_real * KHW
+                    and dwp == wslot.data_ptr() and Cin_real <= Cin_pad and rows >= 1):
+                raise L.SdeHipError(f"WGradReducer: inconsistent job (slab {tuple(slab.shape)}, src offset {None if src is None else src - lo}, "
+                                    f"rows {rows}, Cout {Cout}, KHW {KHW}, Cin_pad {Cin_pad}, Cin_real {Cin_real}, slot {tuple(wslot.shape)})")
+            end += Cout
+            max_k = max(max_k, KHW * Cin_pad)
             items.append(WReduceItem(*it, end))
         arr = (WReduceItem * len(items))(*items)
-        host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
         dev = self.jobs[0][0].device
-        capturing = torch.cuda.is_current_stream_capturing()
-        if capturing:
-            table = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
+        slot = None
+        if torch.cuda.is_current_stream_capturing():
+            # the table's contents are pointers into the graph's pool: reserve it now, fill it right after capture (fill_tables)
+            table = torch.empty(raw.size, dtype=torch.uint8, device=dev)
             self._tables.append(table)
-            self._pending.append((table, host))
+            self._pending.append((table, torch.from_numpy(raw)))
         else:
-            table = host.to(dev)
+            if self._ring is None:
+                self._ring = L.UploadRing(dev)
+            slot = self._ring.acquire(raw.size)
+            table = slot.write(raw)
         _timed("wgrad_reduce", 0.0, 0, lambda: L.check(L.lib().sde_wgrad_reduce_batched(L.ptr(table), len(items), end, max_k, L.stream()),
                                                        "sde_wgrad_reduce_batched"), dict(jobs=len(items)))
+        if slot is not None:
+            slot.release()
         self.jobs, self._seen = [], set()
 
     def fill_tables(self):

@@ -96,8 +96,10 @@ class _PhotoScale(torch.autograd.Function):
         sel = torch.empty(B, h, w, device=dev, dtype=torch.uint8)
         partial = torch.empty(lib.sde_photo_num_blocks(B, h, w, 0), device=dev)
         loss = torch.empty((), device=dev)
-        L.check(lib.sde_photo_fwd(ctypes.byref(d), L.ptr_array(sampled), L.ptr(sel), None, L.ptr(partial), L.ptr(loss), 1.0, 0, L.stream()),
-                "sde_photo_fwd")
+        # algorithmic bytes (fused per scale): target 12 + contexts 12 each + depth 4 per pixel, fp32
+        L.timed("photo_fwd", B * h * w * (16 + 12 * nctx), nctx,
+                lambda: L.check(lib.sde_photo_fwd(ctypes.byref(d), L.ptr_array(sampled), L.ptr(sel), None, L.ptr(partial), L.ptr(loss), 1.0, 0, L.stream()),
+                                "sde_photo_fwd"), dict(B=B, h=h, w=w, moved=B * h * w * (16 + 24 * nctx + 1)))
         ctx.save_for_backward(depth, K, A, sel, *ctxs, *poses, *sampled)
         ctx.cfg = (sx, sy, ssim_w, C1, C2, automask, reduce_mean, nctx)
         return loss
@@ -116,8 +118,10 @@ class _PhotoScale(torch.autograd.Function):
         d_pose = [torch.empty(B, 4, 4, device=dev) for _ in range(nctx)]
         pp = torch.empty(lib.sde_photo_num_blocks(B, h, w, 1) * nctx * 12, device=dev)
         gout = _f32c(gout)
-        L.check(lib.sde_photo_bwd(ctypes.byref(d), L.ptr_array(sampled), L.ptr(sel), L.ptr(gout), 1.0, L.ptr(d_depth), 0, L.ptr(pp),
-                                  L.ptr_array(d_pose), 0, L.stream()), "sde_photo_bwd")
+        # algorithmic bytes: target 12 + (context 12 + saved warped frame 12) per context + depth 4 + arg-min 1 + d_depth 4 per pixel
+        L.timed("photo_bwd", B * h * w * (21 + 24 * nctx), nctx,
+                lambda: L.check(lib.sde_photo_bwd(ctypes.byref(d), L.ptr_array(sampled), L.ptr(sel), L.ptr(gout), 1.0, L.ptr(d_depth), 0, L.ptr(pp),
+                                                  L.ptr_array(d_pose), 0, L.stream()), "sde_photo_bwd"), dict(B=B, h=h, w=w))
         return (d_depth, None, None, None, None, None, None, None, None, None, None) + (None,) * nctx + tuple(d_pose)
 
 
