@@ -163,16 +163,16 @@ int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, in
                    sde_stream_t stream);
 
 /* Deferred form for training loops: sde_conv_wgrad_partial runs the GEMM (+ fold) only and reports where the slabs to sum are;
- * sde_wgrad_reduce_batched then finishes MANY layers in one launch (items: DEVICE array; `end` = exclusive prefix sum of Cout). */
+ * sde_wgrad_reduce_batched then finishes MANY layers in one launch per <= 120 items.  `items` is a HOST array: it is copied into the
+ * kernel arguments, so nothing has to outlive the call. */
 int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, const float** reduce_src,
                            int* reduce_rows, sde_stream_t stream);
 typedef struct sde_wreduce_item {
-    const float* slab; /* reduce_src of sde_conv_wgrad_partial */
-    float* dw;         /* master OIHW fp32 gradient [Cout,Cin_real,KH,KW] */
+    const float* slab; /* reduce_src of sde_conv_wgrad_partial (device) */
+    float* dw;         /* master OIHW fp32 gradient [Cout,Cin_real,KH,KW] (device) */
     int32_t rows, Cout, KHW, Cin_pad, Cin_real, accumulate;
-    int64_t end;
 } sde_wreduce_item;
-int sde_wgrad_reduce_batched(const sde_wreduce_item* items_dev, int n, long total_blocks, int max_k, sde_stream_t stream);
+int sde_wgrad_reduce_batched(const sde_wreduce_item* items, int n, sde_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Layers around the convolutions (NHWC, `dtype` storage, fp32 math)
@@ -225,9 +225,10 @@ int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const floa
 
 /* torch.optim.Adam / AdamW step (projects/MonoDepth2/train.py:L50-57, projects/Supervised/train.py:L77-81) over ONE flat fp32 buffer.
  * Segment s covers [seg_end[s-1], seg_end[s]) with its own lr / weight decay (device arrays, so a captured graph sees updates);
- * bias_corr = device [2] = (1 - beta1^t, 1 - beta2^t); grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+ * bias_corr1/2 = (1 - beta1^t, 1 - beta2^t), by value (the step count lives on the host); grad_scale multiplies g first (1/world_size
+ * after a sum all-reduce). */
 int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
-                  float beta2, float eps, const float* bias_corr, float grad_scale, int decoupled_wd, sde_stream_t stream);
+                  float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale, int decoupled_wd, sde_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -926,35 +926,42 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 
 // The same for many layers in ONE launch: block b finds its (layer, output channel) by binary search in the prefix sums of
 // the layers' Cout.  Used by the training engine, which defers every layer's final slab reduction to the end of a backward phase.
-__global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const sde_wreduce_item* __restrict__ items, int n) {
+// The item table travels BY VALUE in the kernel arguments (<= 4 KB): no device table whose upload / lifetime has to be ordered
+// against a launch that runs long after the host has moved on, and a captured hipGraph node carries it in its parameters.
+constexpr int WREDUCE_MAX = 120;
+struct WReduceArg { const float* slab; float* dw; int end; unsigned short rows, Cout, KHW, Cin_pad, Cin_real, accumulate; };
+static_assert(sizeof(WReduceArg) == 32, "WReduceArg packing");
+struct WReduceBatch { int n, pad; WReduceArg it[WREDUCE_MAX]; };
+
+__global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduceBatch batch) {
     extern __shared__ float sk[];
-    int lo = 0, hi = n - 1;
-    const long b = blockIdx.x;
+    int lo = 0, hi = batch.n - 1;
+    const int b = blockIdx.x;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (items[mid].end > b) hi = mid; else lo = mid + 1;
+        if (batch.it[mid].end > b) hi = mid; else lo = mid + 1;
     }
-    const sde_wreduce_item it = items[lo];
-    const int co = (int)(b - (lo ? items[lo - 1].end : 0));
-    const int K = it.KHW * it.Cin_pad;
-    const size_t total = (size_t)it.Cout * K;
+    const WReduceArg it = batch.it[lo];
+    const int co = b - (lo ? batch.it[lo - 1].end : 0);
+    const int K = (int)it.KHW * it.Cin_pad, Cout = it.Cout, rows = it.rows, KHW = it.KHW, Cin_pad = it.Cin_pad;
+    const size_t total = (size_t)Cout * K;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float* src = it.slab + (size_t)co * K + k;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int sp = 0;
-        for (; sp + 3 < it.rows; sp += 4) {
+        for (; sp + 3 < rows; sp += 4) {
             s0 += src[(size_t)sp * total]; s1 += src[(size_t)(sp + 1) * total];
             s2 += src[(size_t)(sp + 2) * total]; s3 += src[(size_t)(sp + 3) * total];
         }
-        for (; sp < it.rows; ++sp) s0 += src[(size_t)sp * total];
+        for (; sp < rows; ++sp) s0 += src[(size_t)sp * total];
         sk[k] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
-    const int nn = it.Cin_real * it.KHW;
+    const int nn = (int)it.Cin_real * KHW;
     float* o = it.dw + (size_t)co * nn;
     for (int j = threadIdx.x; j < nn; j += 256) {
-        const int ci = j / it.KHW, tap = j - ci * it.KHW;
-        const float v = sk[tap * it.Cin_pad + ci];
+        const int ci = j / KHW, tap = j - ci * KHW;
+        const float v = sk[tap * Cin_pad + ci];
         o[j] = it.accumulate ? o[j] + v : v;
     }
 }
@@ -1312,12 +1319,31 @@ int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int
     return wgrad_partial(d, dy, Cout, ldd, slab, splits, (hipStream_t)stream, g, reduce_src, reduce_rows);
 }
 
-int sde_wgrad_reduce_batched(const sde_wreduce_item* items_dev, int n, long total_blocks, int max_k, sde_stream_t stream) {
-    SDE_CHECK_ARG(items_dev && n > 0 && total_blocks > 0 && max_k > 0, "sde_wgrad_reduce_batched: bad argument");
-    SDE_CHECK_ARG((size_t)max_k * sizeof(float) <= 160 * 1024, "sde_wgrad_reduce_batched: K=%d too large", max_k);
+int sde_wgrad_reduce_batched(const sde_wreduce_item* items, int n, sde_stream_t stream) {
+    SDE_CHECK_ARG(items && n > 0, "sde_wgrad_reduce_batched: bad argument");
     set_reduce_lds_attr();
-    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(256), (size_t)max_k * sizeof(float), (hipStream_t)stream, items_dev, n);
-    SDE_CHECK_LAUNCH("sde_wgrad_reduce_batched");
+    for (int i = 0; i < n; ++i) {
+        const sde_wreduce_item& it = items[i];
+        SDE_CHECK_ARG(it.slab && it.dw && it.rows >= 1 && it.rows <= 65535 && it.Cout >= 1 && it.Cout <= 65535 && it.KHW >= 1 && it.KHW <= 65535 &&
+                          it.Cin_pad >= 1 && it.Cin_pad <= 65535 && it.Cin_real >= 1 && it.Cin_real <= it.Cin_pad,
+                      "sde_wgrad_reduce_batched: item %d out of range", i);
+        SDE_CHECK_ARG((size_t)it.KHW * it.Cin_pad * sizeof(float) <= 160 * 1024, "sde_wgrad_reduce_batched: item %d: K too large", i);
+    }
+    for (int i0 = 0; i0 < n; i0 += WREDUCE_MAX) {
+        WReduceBatch batch;
+        batch.n = n - i0 < WREDUCE_MAX ? n - i0 : WREDUCE_MAX; batch.pad = 0;
+        int end = 0, max_k = 0;
+        for (int i = 0; i < batch.n; ++i) {
+            const sde_wreduce_item& it = items[i0 + i];
+            end += it.Cout;
+            if (it.KHW * it.Cin_pad > max_k) max_k = it.KHW * it.Cin_pad;
+            batch.it[i] = WReduceArg{it.slab, it.dw, end, (unsigned short)it.rows, (unsigned short)it.Cout, (unsigned short)it.KHW,
+                                     (unsigned short)it.Cin_pad, (unsigned short)it.Cin_real, (unsigned short)(it.accumulate != 0)};
+        }
+        for (int i = batch.n; i < WREDUCE_MAX; ++i) batch.it[i] = WReduceArg{nullptr, nullptr, end, 0, 0, 0, 0, 0, 0};
+        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)end), dim3(256), (size_t)max_k * sizeof(float), (hipStream_t)stream, batch);
+        SDE_CHECK_LAUNCH("sde_wgrad_reduce_batched");
+    }
     return SDE_OK;
 }
 

@@ -700,9 +700,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                                                    const long* __restrict__ seg_end, const float* __restrict__ seg_lr, const float* __restrict__ seg_wd, int nseg,
-                                                   float beta1, float beta2, float eps, const float* __restrict__ bias_corr /*[2]: 1-b1^t, 1-b2^t*/,
+                                                   float beta1, float beta2, float eps, float bc1 /* 1-b1^t */, float bc2 /* 1-b2^t */,
                                                    float grad_scale, int decoupled) {
-    const float bc1 = bias_corr[0], bc2 = bias_corr[1];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         int s = 0;
         while (s < nseg - 1 && i >= seg_end[s]) ++s;
@@ -946,10 +945,10 @@ int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const floa
 }
 
 int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
-                  float beta2, float eps, const float* bias_corr, float grad_scale, int decoupled_wd, sde_stream_t stream) {
-    SDE_CHECK_ARG(p && g && m && v && seg_end && seg_lr && seg_wd && bias_corr && n > 0 && nseg > 0, "sde_adam_step: bad argument");
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, bias_corr,
-                       grad_scale, decoupled_wd);
+                  float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale, int decoupled_wd, sde_stream_t stream) {
+    SDE_CHECK_ARG(p && g && m && v && seg_end && seg_lr && seg_wd && n > 0 && nseg > 0 && bias_corr1 > 0.f && bias_corr2 > 0.f, "sde_adam_step: bad argument");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, bias_corr1,
+                       bias_corr2, grad_scale, decoupled_wd);
     SDE_CHECK_LAUNCH("sde_adam_step");
     return SDE_OK;
 }

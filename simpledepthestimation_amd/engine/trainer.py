@@ -17,11 +17,9 @@ MI355X-first choices
 """
 import math
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
-from ..hip import lib as HL
 from ..hip import nn as HN
 
 
@@ -89,7 +87,6 @@ class HipTrainer:
         self.seg_end = torch.tensor(seg_end, dtype=torch.long, device=dev)
         self.seg_lr = torch.tensor([g.lr for g in self.groups], dtype=torch.float32, device=dev)
         self.seg_wd = torch.tensor([g.weight_decay for g in self.groups], dtype=torch.float32, device=dev)
-        self._ring = None
         self.t = 0
         # ---- gradient buckets for the all-reduce (contiguous slices of the flat gradient)
         per = max(1, int(bucket_mb * (1 << 20) / 4))
@@ -175,19 +172,9 @@ class HipTrainer:
     def _optimizer(self):
         self.t += 1
         b1, b2 = self.betas
-        bc = np.array([1.0 - b1 ** self.t, 1.0 - b2 ** self.t], dtype=np.float32)
-        slot = None
-        if self.device.type == "cuda":
-            if self._ring is None:
-                self._ring = HL.UploadRing(self.device)
-            slot = self._ring.acquire(8)                       # per-step scalars: pinned, stream-ordered, no buffer rewritten in flight
-            bias_corr = slot.write(bc.view(np.uint8)).view(torch.float32)
-        else:
-            bias_corr = torch.from_numpy(bc)
+        bias_corr = (1.0 - b1 ** self.t, 1.0 - b2 ** self.t)       # by value: no per-step device scalar to keep ordered with the launch
         self._adam_fn(self.pflat, self.gflat, self.m, self.v, self.seg_end, self.seg_lr, self.seg_wd, bias_corr, b1, b2, self.eps,
                       1.0 / self.world, self.adamw)
-        if slot is not None:
-            slot.release()
 
     # ------------------------------------------------------------------------------------------------------------
     def _to_static(self, batch):
@@ -237,8 +224,6 @@ class HipTrainer:
             self._graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_b, pool=self._graph.pool()):
                 self._backward_rest()
-        if self._wreduce is not None:
-            self._wreduce.fill_tables()
         return self
 
     def step(self, batch):

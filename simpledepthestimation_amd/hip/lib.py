@@ -59,49 +59,6 @@ def timed(kind, work, variant, call, meta=None):
     return r
 
 
-class UploadRing:
-    """Small host->device tables (kernel item tables, per-step scalars) without lifetime hazards.
-
-    Each slot owns a pinned staging buffer and a device buffer that are never returned to the caching allocator, so neither can be
-    recycled under a kernel that has been launched but not run yet.  The upload is a pinned hipMemcpyAsync (ordered on the current
-    stream); a slot is reused only after the event recorded behind its last consumer has completed.  (A device tensor made by a
-    blocking pageable .to(device) and dropped right after the launch was observed to be overwritten before the kernel ran.)"""
-
-    class Slot:
-        def __init__(self, nbytes, device):
-            self.host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-            self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self.event = None
-
-        def write(self, raw):
-            """raw: numpy uint8 array; returns the device view holding it (valid until release() + one trip round the ring)."""
-            n = raw.size
-            self.host[:n].copy_(torch.from_numpy(raw))
-            self.dev[:n].copy_(self.host[:n], non_blocking=True)
-            return self.dev[:n]
-
-        def release(self):
-            self.event = torch.cuda.Event()
-            self.event.record()
-
-    def __init__(self, device, depth=8):
-        self.device, self.depth, self.slots, self.i = device, depth, [None] * depth, 0
-        self._retired = []
-
-    def acquire(self, nbytes):
-        k = self.i
-        self.i = (self.i + 1) % self.depth
-        slot = self.slots[k]
-        if slot is not None and slot.event is not None:
-            slot.event.synchronize()
-        if slot is None or slot.host.numel() < nbytes:
-            if slot is not None:
-                self._retired.append(slot)
-            slot = UploadRing.Slot(max(4096, 2 * nbytes), self.device)
-            self.slots[k] = slot
-        return slot
-
-
 def register_protos(protos):
     """Other binding modules (conv, norm, ...) add their prototypes here before first use."""
     _PROTOS.update(protos)

@@ -33,7 +33,7 @@ L.register_protos({
     "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_wgrad": ([POINTER(ConvDesc), _P, _I, _I, _I, _P, _I, _P, _I, _P], c_int),
     "sde_conv_wgrad_partial": ([POINTER(ConvDesc), _P, _I, _I, _P, _I, POINTER(c_void_p), POINTER(c_int), _P], c_int),
-    "sde_wgrad_reduce_batched": ([_P, _I, ctypes.c_long, _I, _P], c_int),
+    "sde_wgrad_reduce_batched": ([_P, _I, _P], c_int),
     "sde_prep_input": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_bn_finalize": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P], c_int),
     "sde_bn_eval_params": ([_P, _P, _P, _P, _F, _I, _P, _P], c_int),
@@ -48,7 +48,7 @@ L.register_protos({
     "sde_depth_head_bwd": ([_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P], c_int),
     "sde_gn_relu_fwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P], c_int),
     "sde_gn_relu_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P], c_int),
-    "sde_adam_step": ([_P, _P, _P, _P, _LG, _P, _P, _P, _I, _F, _F, _F, _P, _F, _I, _P], c_int),
+    "sde_adam_step": ([_P, _P, _P, _P, _LG, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _I, _P], c_int),
 })
 
 
@@ -269,7 +269,7 @@ class _Conv2d(torch.autograd.Function):
 
 class WReduceItem(Structure):
     _fields_ = [("slab", c_void_p), ("dw", c_void_p), ("rows", c_int32), ("Cout", c_int32), ("KHW", c_int32), ("Cin_pad", c_int32),
-                ("Cin_real", c_int32), ("accumulate", c_int32), ("end", ctypes.c_int64)]
+                ("Cin_real", c_int32), ("accumulate", c_int32)]
 
 
 class WGradReducer:
@@ -277,14 +277,11 @@ class WGradReducer:
 
     While installed (`WGRAD_DEFER = reducer`, done by HipTrainer around backward) each _Conv2d.backward runs only the GEMM (+fold) and
     registers its slabs here; flush() sums them all into the flat gradient.  Nothing persists across steps: slabs come from the caching
-    allocator (the graph pool under capture) and are released at flush; the item table goes through an UploadRing slot (eager) or is
-    reserved during hipGraph capture and filled right after it (fill_tables()), since its contents are only pointers."""
+    allocator (the graph pool under capture) and are released at flush; the item table is a host array that the C side copies into the
+    kernel arguments, so there is no device table to upload, keep alive or re-fill after graph capture."""
 
     def __init__(self):
         self.jobs, self._seen = [], set()
-        self._tables = []          # device tables of captured launches, kept alive for the graph's replays
-        self._pending = []
-        self._ring = None
 
     def accepts(self, wslot):
         # a weight used twice in one phase (shared modules) must not be accumulated by two blocks of one launch: the second use reduces at once
@@ -297,8 +294,7 @@ class WGradReducer:
     def flush(self):
         if not self.jobs:
             return
-        import numpy as np
-        items, end, max_k = [], 0, 0
+        items = []
         for slab, wslot, it in self.jobs:
             src, dwp, rows, Cout, KHW, Cin_pad, Cin_real, _ = it
             # host-side operand check: the rows to sum must lie inside the slab tensor, the gradient slot must have the OIHW size
@@ -307,34 +303,11 @@ class WGradReducer:
                     and dwp == wslot.data_ptr() and Cin_real <= Cin_pad and rows >= 1):
                 raise L.SdeHipError(f"WGradReducer: inconsistent job (slab {tuple(slab.shape)}, src offset {None if src is None else src - lo}, "
                                     f"rows {rows}, Cout {Cout}, KHW {KHW}, Cin_pad {Cin_pad}, Cin_real {Cin_real}, slot {tuple(wslot.shape)})")
-            end += Cout
-            max_k = max(max_k, KHW * Cin_pad)
-            items.append(WReduceItem(*it, end))
+            items.append(WReduceItem(*it))
         arr = (WReduceItem * len(items))(*items)
-        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-        dev = self.jobs[0][0].device
-        slot = None
-        if torch.cuda.is_current_stream_capturing():
-            # the table's contents are pointers into the graph's pool: reserve it now, fill it right after capture (fill_tables)
-            table = torch.empty(raw.size, dtype=torch.uint8, device=dev)
-            self._tables.append(table)
-            self._pending.append((table, torch.from_numpy(raw)))
-        else:
-            if self._ring is None:
-                self._ring = L.UploadRing(dev)
-            slot = self._ring.acquire(raw.size)
-            table = slot.write(raw)
-        _timed("wgrad_reduce", 0.0, 0, lambda: L.check(L.lib().sde_wgrad_reduce_batched(L.ptr(table), len(items), end, max_k, L.stream()),
-                                                       "sde_wgrad_reduce_batched"), dict(jobs=len(items)))
-        if slot is not None:
-            slot.release()
+        _timed("wgrad_reduce", 0.0, 0, lambda: L.check(L.lib().sde_wgrad_reduce_batched(arr, len(items), L.stream()), "sde_wgrad_reduce_batched"),
+               dict(jobs=len(items)))
         self.jobs, self._seen = [], set()
-
-    def fill_tables(self):
-        """After graph capture: write the item tables the captured reduce launches read."""
-        for table, host in self._pending:
-            table.copy_(host)
-        self._pending = []
 
 
 WGRAD_DEFER = None      # HipTrainer installs a WGradReducer around backward
@@ -573,4 +546,4 @@ def group_norm_relu(x, gamma, beta, groups=16, eps=1e-5, relu=True):
 def adam_step(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, decoupled_wd=False):
     n = p.numel()
     L.check(L.lib().sde_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, L.ptr(seg_end), L.ptr(seg_lr), L.ptr(seg_wd), seg_end.numel(), beta1, beta2, eps,
-                                  L.ptr(bias_corr), grad_scale, int(decoupled_wd), L.stream()), "sde_adam_step")
+                                  float(bias_corr[0]), float(bias_corr[1]), grad_scale, int(decoupled_wd), L.stream()), "sde_adam_step")
