@@ -162,15 +162,14 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout);
 int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, int Cin_real, float* slab, int splits, float* dw, int accumulate,
                    sde_stream_t stream);
 
-/* Deferred form for training loops: sde_conv_wgrad_partial runs the GEMM (+ fold) only and reports where the slabs to sum are;
- * sde_wgrad_reduce_batched then finishes MANY layers in one launch per <= 120 items.  `items` is a HOST array: it is copied into the
- * kernel arguments, so nothing has to outlive the call. */
-int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, const float** reduce_src,
-                           int* reduce_rows, sde_stream_t stream);
+/* Deferred form for training loops: sde_conv_wgrad_partial runs the GEMM only (slab: [splits][Cout][KH*KW*Cin], no scratch rows);
+ * sde_wgrad_reduce_batched then sums the slabs of MANY layers in one launch per <= 120 items, in the same order as sde_conv_wgrad
+ * (results are bit-identical).  `items` is a HOST array: it is copied into the kernel arguments, so nothing has to outlive the call. */
+int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, sde_stream_t stream);
 typedef struct sde_wreduce_item {
-    const float* slab; /* reduce_src of sde_conv_wgrad_partial (device) */
+    const float* slab; /* the slab stack sde_conv_wgrad_partial filled (device) */
     float* dw;         /* master OIHW fp32 gradient [Cout,Cin_real,KH,KW] (device) */
-    int32_t rows, Cout, KHW, Cin_pad, Cin_real, accumulate;
+    int32_t rows /* = splits */, Cout, KHW, Cin_pad, Cin_real, accumulate;
 } sde_wreduce_item;
 int sde_wgrad_reduce_batched(const sde_wreduce_item* items, int n, sde_stream_t stream);
 

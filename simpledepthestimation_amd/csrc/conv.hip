@@ -900,7 +900,7 @@ __global__ void __launch_bounds__(256) slab_fold_kernel(const float* __restrict_
 // contiguous (the [tap][ci] -> [ci][tap] transpose happens in LDS).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int KHW, int Cin_pad,
                                                            int Cin_real, float* __restrict__ dw, int accumulate) {
-    extern __shared__ float sk[];   // [KHW * Cin_pad]
+    extern __shared__ __attribute__((aligned(16))) float sk[];   // [KHW * Cin_pad]
     const int co = blockIdx.x, K = KHW * Cin_pad;
     const size_t total = (size_t)Cout * K;
     for (int k = threadIdx.x; k < K; k += 256) {
@@ -929,12 +929,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // The item table travels BY VALUE in the kernel arguments (<= 4 KB): no device table whose upload / lifetime has to be ordered
 // against a launch that runs long after the host has moved on, and a captured hipGraph node carries it in its parameters.
 constexpr int WREDUCE_MAX = 120;
-struct WReduceArg { const float* slab; float* dw; int end; unsigned short rows, Cout, KHW, Cin_pad, Cin_real, accumulate; };
+struct WReduceArg { const float* slab; float* dw; int end; unsigned short splits, chunk, Cout, KHW, Cin_pad, Cin_real /* | 0x8000: accumulate */; };
 static_assert(sizeof(WReduceArg) == 32, "WReduceArg packing");
 struct WReduceBatch { int n, pad; WReduceArg it[WREDUCE_MAX]; };
 
+// Tall slab stacks are summed in the SAME order as slab_fold_kernel + wgrad_reduce_kernel would (chunks of `chunk` rows, even / odd
+// rows in two chains; then the <= SDE_WGRAD_FOLD_ROWS chunk sums four ways), so deferred and immediate reductions agree bit for bit.
 __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduceBatch batch) {
-    extern __shared__ float sk[];
+    extern __shared__ __attribute__((aligned(16))) float sk[];
     int lo = 0, hi = batch.n - 1;
     const int b = blockIdx.x;
     while (lo < hi) {
@@ -943,26 +945,46 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduce
     }
     const WReduceArg it = batch.it[lo];
     const int co = b - (lo ? batch.it[lo - 1].end : 0);
-    const int K = (int)it.KHW * it.Cin_pad, Cout = it.Cout, rows = it.rows, KHW = it.KHW, Cin_pad = it.Cin_pad;
-    const size_t total = (size_t)Cout * K;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float* src = it.slab + (size_t)co * K + k;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int sp = 0;
-        for (; sp + 3 < rows; sp += 4) {
-            s0 += src[(size_t)sp * total]; s1 += src[(size_t)(sp + 1) * total];
-            s2 += src[(size_t)(sp + 2) * total]; s3 += src[(size_t)(sp + 3) * total];
+    const int KHW = it.KHW, Cin_pad = it.Cin_pad, K = KHW * Cin_pad, Cout = it.Cout, splits = it.splits, chunk = it.chunk;
+    const size_t total4 = (size_t)Cout * K / 4;                     // K is a multiple of 4: rows are walked as float4 (16 B per lane)
+    auto add4 = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    for (int k4 = threadIdx.x; k4 < K / 4; k4 += 256) {
+        const float4* src = reinterpret_cast<const float4*>(it.slab) + (size_t)co * (K / 4) + k4;
+        const float4 z = {0.f, 0.f, 0.f, 0.f};
+        float4 s0 = z, s1 = z, s2 = z, s3 = z;
+        if (chunk == 1) {
+            int sp = 0;
+            for (; sp + 3 < splits; sp += 4) {
+                add4(s0, src[(size_t)sp * total4]); add4(s1, src[(size_t)(sp + 1) * total4]);
+                add4(s2, src[(size_t)(sp + 2) * total4]); add4(s3, src[(size_t)(sp + 3) * total4]);
+            }
+            for (; sp < splits; ++sp) add4(s0, src[(size_t)sp * total4]);
+        } else {
+            auto part = [&](int ro) {
+                const int r0 = ro * chunk, r1 = min(splits, r0 + chunk);
+                float4 a = z, c = z;
+                int r = r0;
+                for (; r + 1 < r1; r += 2) { add4(a, src[(size_t)r * total4]); add4(c, src[(size_t)(r + 1) * total4]); }
+                if (r < r1) add4(a, src[(size_t)r * total4]);
+                add4(a, c);
+                return a;
+            };
+            const int rows = (splits + chunk - 1) / chunk;
+            int ro = 0;
+            for (; ro + 3 < rows; ro += 4) { add4(s0, part(ro)); add4(s1, part(ro + 1)); add4(s2, part(ro + 2)); add4(s3, part(ro + 3)); }
+            for (; ro < rows; ++ro) add4(s0, part(ro));
         }
-        for (; sp < rows; ++sp) s0 += src[(size_t)sp * total];
-        sk[k] = (s0 + s1) + (s2 + s3);
+        add4(s0, s1); add4(s2, s3); add4(s0, s2);
+        reinterpret_cast<float4*>(sk)[k4] = s0;
     }
     __syncthreads();
-    const int nn = (int)it.Cin_real * KHW;
+    const int cin_real = it.Cin_real & 0x7fff, accumulate = it.Cin_real >> 15;
+    const int nn = cin_real * KHW;
     float* o = it.dw + (size_t)co * nn;
     for (int j = threadIdx.x; j < nn; j += 256) {
         const int ci = j / KHW, tap = j - ci * KHW;
         const float v = sk[tap * Cin_pad + ci];
-        o[j] = it.accumulate ? o[j] + v : v;
+        o[j] = accumulate ? o[j] + v : v;
     }
 }
 
@@ -1257,7 +1279,7 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
 
 // GEMM + (for tall slab stacks) fold.  On return *red_src / *red_rows say where the <= SDE_WGRAD_FOLD_ROWS (or `splits`) slabs to sum are.
 static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, hipStream_t s, Gather& g,
-                         const float** red_src, int* red_rows) {
+                         const float** red_src, int* red_rows, bool fold) {
     WGradP p;
     int rc = fill_gather(d, p.g, "sde_conv_wgrad");
     if (rc) return rc;
@@ -1274,7 +1296,7 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     SDE_CHECK_LAUNCH("sde_conv_wgrad");
     SDE_CHECK_ARG((size_t)p.g.Ktot * sizeof(float) <= 160 * 1024, "sde_conv_wgrad: K=%d too large for the reduce kernel's LDS transpose", p.g.Ktot);
     *red_src = slab; *red_rows = splits;
-    if (splits > SDE_WGRAD_FOLD_ROWS) {     // fold into the SDE_WGRAD_FOLD_ROWS scratch rows behind the slab stack
+    if (fold && splits > SDE_WGRAD_FOLD_ROWS) {     // fold into the SDE_WGRAD_FOLD_ROWS scratch rows behind the slab stack
         const size_t width4 = (size_t)Cout * p.g.Ktot / 4;      // Ktot is a multiple of 4 elements
         const int chunk = sde_cdiv(splits, SDE_WGRAD_FOLD_ROWS);
         *red_rows = sde_cdiv(splits, chunk);
@@ -1302,7 +1324,7 @@ int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, in
     hipStream_t s = (hipStream_t)stream;
     Gather g;
     const float* red_src; int red_rows;
-    int rc = wgrad_partial(d, dy, Cout, ldd, slab, splits, s, g, &red_src, &red_rows);
+    int rc = wgrad_partial(d, dy, Cout, ldd, slab, splits, s, g, &red_src, &red_rows, true);
     if (rc) return rc;
     SDE_CHECK_ARG(Cin_real >= 1 && Cin_real <= g.Cin, "sde_conv_wgrad: bad Cin_real=%d", Cin_real);
     set_reduce_lds_attr();
@@ -1312,11 +1334,11 @@ int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, in
     return SDE_OK;
 }
 
-int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, const float** reduce_src,
-                           int* reduce_rows, sde_stream_t stream) {
-    SDE_CHECK_ARG(d && dy && slab && reduce_src && reduce_rows, "sde_conv_wgrad_partial: null pointer");
+int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && dy && slab, "sde_conv_wgrad_partial: null pointer");
     Gather g;
-    return wgrad_partial(d, dy, Cout, ldd, slab, splits, (hipStream_t)stream, g, reduce_src, reduce_rows);
+    const float* src; int rows;
+    return wgrad_partial(d, dy, Cout, ldd, slab, splits, (hipStream_t)stream, g, &src, &rows, false);
 }
 
 int sde_wgrad_reduce_batched(const sde_wreduce_item* items, int n, sde_stream_t stream) {
@@ -1325,9 +1347,10 @@ int sde_wgrad_reduce_batched(const sde_wreduce_item* items, int n, sde_stream_t 
     for (int i = 0; i < n; ++i) {
         const sde_wreduce_item& it = items[i];
         SDE_CHECK_ARG(it.slab && it.dw && it.rows >= 1 && it.rows <= 65535 && it.Cout >= 1 && it.Cout <= 65535 && it.KHW >= 1 && it.KHW <= 65535 &&
-                          it.Cin_pad >= 1 && it.Cin_pad <= 65535 && it.Cin_real >= 1 && it.Cin_real <= it.Cin_pad,
+                          it.Cin_pad >= 1 && it.Cin_pad <= 32767 && it.Cin_real >= 1 && it.Cin_real <= it.Cin_pad,
                       "sde_wgrad_reduce_batched: item %d out of range", i);
         SDE_CHECK_ARG((size_t)it.KHW * it.Cin_pad * sizeof(float) <= 160 * 1024, "sde_wgrad_reduce_batched: item %d: K too large", i);
+        SDE_CHECK_ARG((it.KHW * it.Cin_pad) % 4 == 0 && ((uintptr_t)it.slab & 15) == 0, "sde_wgrad_reduce_batched: item %d: K %% 4 != 0 or unaligned slab", i);
     }
     for (int i0 = 0; i0 < n; i0 += WREDUCE_MAX) {
         WReduceBatch batch;
@@ -1337,8 +1360,9 @@ int sde_wgrad_reduce_batched(const sde_wreduce_item* items, int n, sde_stream_t 
             const sde_wreduce_item& it = items[i0 + i];
             end += it.Cout;
             if (it.KHW * it.Cin_pad > max_k) max_k = it.KHW * it.Cin_pad;
-            batch.it[i] = WReduceArg{it.slab, it.dw, end, (unsigned short)it.rows, (unsigned short)it.Cout, (unsigned short)it.KHW,
-                                     (unsigned short)it.Cin_pad, (unsigned short)it.Cin_real, (unsigned short)(it.accumulate != 0)};
+            const int chunk = it.rows > SDE_WGRAD_FOLD_ROWS ? sde_cdiv(it.rows, SDE_WGRAD_FOLD_ROWS) : 1;     // as sde_conv_wgrad folds
+            batch.it[i] = WReduceArg{it.slab, it.dw, end, (unsigned short)it.rows, (unsigned short)chunk, (unsigned short)it.Cout, (unsigned short)it.KHW,
+                                     (unsigned short)it.Cin_pad, (unsigned short)(it.Cin_real | (it.accumulate ? 0x8000 : 0))};
         }
         for (int i = batch.n; i < WREDUCE_MAX; ++i) batch.it[i] = WReduceArg{nullptr, nullptr, end, 0, 0, 0, 0, 0, 0};
         hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)end), dim3(256), (size_t)max_k * sizeof(float), (hipStream_t)stream, batch);

@@ -551,6 +551,19 @@ __global__ void __launch_bounds__(256) depth_head_bwd_kernel(const T* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int GN_CHUNKS = 16;
 
+// The 256/C threads that walked channel c = tid % C combine their partial sums in thread order (no float atomics: the statistics,
+// and with them every PoseNet gradient, are bit-reproducible from run to run).  All 256 threads must call it; sh = [2][C].
+__device__ __forceinline__ void fixed_order_channel_sum(float a1, float a2, int C, float* sh) {
+    __shared__ float red[512];
+    red[threadIdx.x] = a1; red[256 + threadIdx.x] = a2;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int j = threadIdx.x; j < 256; j += C) { t1 += red[j]; t2 += red[256 + j]; }
+        sh[threadIdx.x] = t1; sh[C + threadIdx.x] = t2;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ part /*[B][GN_CHUNKS][C][2]*/) {
     extern __shared__ float sh[];   // [2][C]
@@ -566,7 +579,8 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
     if (256 % C == 0) {
         const int c = threadIdx.x % C;
         for (long i = threadIdx.x; i < total; i += 256) { const float v = (float)base[i]; a1 += v; a2 += v * v; }
-        atomicAdd(&sh[c], a1); atomicAdd(&sh[C + c], a2);
+        (void)c;
+        fixed_order_channel_sum(a1, a2, C, sh);
     } else {
         for (long i = threadIdx.x; i < total; i += 256) {
             const int c = (int)(i % C);
@@ -634,7 +648,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
             const float xh = ((float)x[base + i] - st[0]) * st[1];
             a1 += d; a2 += d * xh;
         }
-        atomicAdd(&sh[c], a1); atomicAdd(&sh[C + c], a2);
+        fixed_order_channel_sum(a1, a2, C, sh);
     } else {
         for (long i = threadIdx.x; i < total; i += 256) {
             const int c = (int)(i % C);

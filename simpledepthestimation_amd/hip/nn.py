@@ -32,7 +32,7 @@ L.register_protos({
     "sde_conv_set_halo_min_blocks": ([_I], c_int),
     "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_wgrad": ([POINTER(ConvDesc), _P, _I, _I, _I, _P, _I, _P, _I, _P], c_int),
-    "sde_conv_wgrad_partial": ([POINTER(ConvDesc), _P, _I, _I, _P, _I, POINTER(c_void_p), POINTER(c_int), _P], c_int),
+    "sde_conv_wgrad_partial": ([POINTER(ConvDesc), _P, _I, _I, _P, _I, _P], c_int),
     "sde_wgrad_reduce_batched": ([_P, _I, _P], c_int),
     "sde_prep_input": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_bn_finalize": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P], c_int),
@@ -223,16 +223,15 @@ class _Conv2d(torch.autograd.Function):
             else:
                 import contextlib
                 wctx = contextlib.nullcontext()
-            slab = torch.empty(splits + (FOLD_ROWS if splits > FOLD_ROWS else 0), Cout, KH * KW * (C0 + C1), device=dev)   # + fold scratch rows
             dw = wslot if wslot is not None else torch.empty_like(weight)
             defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and WGRAD_DEFER.accepts(wslot)) else None
+            # immediate reduction folds tall stacks into FOLD_ROWS scratch rows behind the slabs; the deferred one needs no scratch
+            slab = torch.empty(splits + (FOLD_ROWS if (defer is None and splits > FOLD_ROWS) else 0), Cout, KH * KW * (C0 + C1), device=dev)
             with wctx:
                 if defer is not None:
-                    src, rows = c_void_p(), c_int()
-                    _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits,
-                                                                                         ctypes.byref(src), ctypes.byref(rows), L.stream()),
+                    _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits, L.stream()),
                                                               "sde_conv_wgrad_partial"), meta)
-                    defer.add(slab, src.value, rows.value, wslot, Cout, KH * KW, C0 + C1, Cin)
+                    defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin)
                 else:
                     _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
                                                                                  int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
