@@ -1268,7 +1268,8 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     const int Ktot = d->KH * d->KW * (d->C0 + d->C1);
     const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, 128);
     const int BR = d->dtype == SDE_BF16 ? 64 : 32;
-    long want = (512 + tiles - 1) / tiles;                  // ~2 workgroups per CU
+    static const long target = [] { const char* e = getenv("SDE_WGRAD_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 256L; }();
+    long want = (target + tiles - 1) / tiles;               // default 256 (one workgroup per CU): measured best end to end -- every extra split is another fp32 slab through HBM
     const long max_by_rows = (M + 4 * BR - 1) / (4 * BR);   // at least 4 stages per split
     if (want > max_by_rows) want = max_by_rows;
     const long max_by_mem = (256L << 20) / ((long)Cout * Ktot * 4);   // slab <= 256 MiB
