@@ -155,8 +155,8 @@ int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy);
 int sde_conv_set_halo_min_blocks(int min_blocks); /* tile the dispatcher picks: BM*1000 + BN (profiling aid) */
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).
- * slab: caller workspace [splits + SDE_WGRAD_FOLD_ROWS][Cout][KH*KW*(C0+C1)] fp32, splits = sde_conv_wgrad_splits(d, Cout)
- * (the extra rows are scratch for folding tall slab stacks before the final fixed-order sum). */
+ * slab: caller workspace [splits][Cout][KH*KW*(C0+C1)] fp32, splits = sde_conv_wgrad_splits(d, Cout): one fp32 partial per pixel range,
+ * summed in a fixed order (stacks taller than SDE_WGRAD_FOLD_ROWS as that many chunk sums first) -- bit-reproducible, no atomics. */
 #define SDE_WGRAD_FOLD_ROWS 16
 int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout);
 int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, int Cin_real, float* slab, int splits, float* dw, int accumulate,
@@ -215,8 +215,8 @@ int sde_depth_head_fwd(const void* y, int B, int H, int W, int ld, float min_dep
 int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, void* dy,
                        sde_stream_t stream);
 
-/* nn.GroupNorm(G) + nn.ReLU (PoseNet.py:L13-20).  part: [B][16][C][2] workspace, gnp: [B][G][2] (mean, rstd) saved for backward,
- * coef: [B][G][2] workspace. */
+/* nn.GroupNorm(G) + activation: relu = 0 none, 1 nn.ReLU (PoseNet.py:L13-20), 2 nn.ELU (layers01.py:L33-40).
+ * part: [B][16][C][2] workspace, gnp: [B][G][2] (mean, rstd) saved for backward, coef: [B][G][2] workspace. */
 int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype, float* part, float* gnp,
                     void* out, sde_stream_t stream);
 int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,
@@ -226,6 +226,16 @@ int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const floa
  * Segment s covers [seg_end[s-1], seg_end[s]) with its own lr / weight decay (device arrays, so a captured graph sees updates);
  * bias_corr1/2 = (1 - beta1^t, 1 - beta2^t), by value (the step count lives on the host); grad_scale multiplies g first (1/world_size
  * after a sum all-reduce). */
+/* ---------------------------------------------------------------------------------------------------
+ * PackNet's 3-D convolution (layers01.py:L223-298): x.unsqueeze(1) -> nn.Conv3d(1, 8, 3, padding=1) -> view(b, 8*D, h, w) on NHWC data:
+ * y[b,h,w,f*D+ch] = bias[f] + sum w[f][kd][kh][kw] x[b,h+kh-1,w+kw-1,ch+kd-1].  w: [8][3][3][3] fp32 (torch's [8,1,3,3,3]), D % (16 B) == 0.
+ * wgrad: part = workspace [sde_conv3d_wgrad_num_blocks()][224] floats; dw [8*27], dbias [8] (may be NULL). */
+int sde_conv3d_fwd(const void* x, const float* w, const float* bias, int B, int H, int W, int D, int dtype, void* y, sde_stream_t stream);
+int sde_conv3d_dgrad(const void* dy, const float* w, int B, int H, int W, int D, int dtype, void* dx, sde_stream_t stream);
+int sde_conv3d_wgrad_num_blocks(int B, int H, int W, int D, int dtype);
+int sde_conv3d_wgrad(const void* x, const void* dy, int B, int H, int W, int D, int dtype, float* part, float* dw, float* dbias, int accumulate,
+                     sde_stream_t stream);
+
 int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
                   float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale, int decoupled_wd, sde_stream_t stream);
 

@@ -875,68 +875,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_kernel(WGradP p) {
             }
 }
 
-// Tall slab stacks (many pixel splits) are first folded to <= SDE_WGRAD_FOLD_ROWS rows: out[ro] = sum of chunk ro of the rows.
-__global__ void __launch_bounds__(256) slab_fold_kernel(const float* __restrict__ slab, int rows, size_t width4, int chunk, float* __restrict__ out) {
-    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= width4) return;
-    const int ro = blockIdx.y, r0 = ro * chunk, r1 = min(rows, r0 + chunk);
-    float4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-    int r = r0;
-    for (; r + 1 < r1; r += 2) {
-        const float4 u = reinterpret_cast<const float4*>(slab)[(size_t)r * width4 + c];
-        const float4 v = reinterpret_cast<const float4*>(slab)[(size_t)(r + 1) * width4 + c];
-        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
-    }
-    if (r < r1) {
-        const float4 u = reinterpret_cast<const float4*>(slab)[(size_t)r * width4 + c];
-        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
-    }
-    reinterpret_cast<float4*>(out)[(size_t)ro * width4 + c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-}
-
-// Sum the slabs in fixed order and write the master OIHW fp32 gradient (skipping padded input channels).
-// One workgroup per output channel: the K-major sums go through LDS so that both the slab reads and the OIHW writes are
-// contiguous (the [tap][ci] -> [ci][tap] transpose happens in LDS).
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Cout, int KHW, int Cin_pad,
-                                                           int Cin_real, float* __restrict__ dw, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) float sk[];   // [KHW * Cin_pad]
-    const int co = blockIdx.x, K = KHW * Cin_pad;
-    const size_t total = (size_t)Cout * K;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float* src = slab + (size_t)co * K + k;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int sp = 0;
-        for (; sp + 3 < splits; sp += 4) {
-            s0 += src[(size_t)sp * total]; s1 += src[(size_t)(sp + 1) * total];
-            s2 += src[(size_t)(sp + 2) * total]; s3 += src[(size_t)(sp + 3) * total];
-        }
-        for (; sp < splits; ++sp) s0 += src[(size_t)sp * total];
-        sk[k] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    const int n = Cin_real * KHW;
-    float* o = dw + (size_t)co * n;
-    for (int j = threadIdx.x; j < n; j += 256) {
-        const int ci = j / KHW, tap = j - ci * KHW;
-        const float v = sk[tap * Cin_pad + ci];
-        o[j] = accumulate ? o[j] + v : v;
-    }
-}
-
-// The same for many layers in ONE launch: block b finds its (layer, output channel) by binary search in the prefix sums of
-// the layers' Cout.  Used by the training engine, which defers every layer's final slab reduction to the end of a backward phase.
-// The item table travels BY VALUE in the kernel arguments (<= 4 KB): no device table whose upload / lifetime has to be ordered
-// against a launch that runs long after the host has moved on, and a captured hipGraph node carries it in its parameters.
+// Sum the slabs in a fixed order and write the master OIHW fp32 gradient (skipping padded input channels), for MANY layers in
+// ONE launch: block b finds its (layer, output channel) by binary search in the prefix sums of the layers' Cout.
+//   * one workgroup per output channel; the K-major sums go through LDS so that both the slab reads (float4 rows) and the OIHW
+//     writes are contiguous -- the [tap][ci] -> [ci][tap] transpose happens in LDS, in chunks of input channels when K*4 B
+//     exceeds the LDS budget (PackNet's 16384-channel layers have K = 147456);
+//   * tall slab stacks are summed as chunks of `chunk` rows (even / odd rows in two chains), then the <= SDE_WGRAD_FOLD_ROWS
+//     chunk sums four ways: fixed order, bit-reproducible;
+//   * the item table travels BY VALUE in the kernel arguments (<= 4 KB): no device table whose upload / lifetime has to be
+//     ordered against a launch that runs long after the host has moved on; a captured hipGraph node carries it in its parameters.
 constexpr int WREDUCE_MAX = 120;
+constexpr int WREDUCE_LDS_FLOATS = 16384;        // 64 KB: two workgroups per CU
 struct WReduceArg { const float* slab; float* dw; int end; unsigned short splits, chunk, Cout, KHW, Cin_pad, Cin_real /* | 0x8000: accumulate */; };
 static_assert(sizeof(WReduceArg) == 32, "WReduceArg packing");
-struct WReduceBatch { int n, pad; WReduceArg it[WREDUCE_MAX]; };
+struct WReduceBatch { int n, lds_floats; WReduceArg it[WREDUCE_MAX]; };
 
-// Tall slab stacks are summed in the SAME order as slab_fold_kernel + wgrad_reduce_kernel would (chunks of `chunk` rows, even / odd
-// rows in two chains; then the <= SDE_WGRAD_FOLD_ROWS chunk sums four ways), so deferred and immediate reductions agree bit for bit.
+__host__ __device__ inline int wreduce_cb(int KHW, int Cin_pad, int lds_floats) {      // input channels per LDS chunk (multiple of 4)
+    const int cb = (lds_floats / KHW) & ~3;
+    return cb < Cin_pad ? cb : Cin_pad;
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduceBatch batch) {
-    extern __shared__ __attribute__((aligned(16))) float sk[];
+    extern __shared__ __attribute__((aligned(16))) float sk[];      // [KHW][cb]
     int lo = 0, hi = batch.n - 1;
     const int b = blockIdx.x;
     while (lo < hi) {
@@ -946,45 +906,52 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduce
     const WReduceArg it = batch.it[lo];
     const int co = b - (lo ? batch.it[lo - 1].end : 0);
     const int KHW = it.KHW, Cin_pad = it.Cin_pad, K = KHW * Cin_pad, Cout = it.Cout, splits = it.splits, chunk = it.chunk;
+    const int cin_real = it.Cin_real & 0x7fff, accumulate = it.Cin_real >> 15;
+    const int CB = wreduce_cb(KHW, Cin_pad, batch.lds_floats);
     const size_t total4 = (size_t)Cout * K / 4;                     // K is a multiple of 4: rows are walked as float4 (16 B per lane)
     auto add4 = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
-    for (int k4 = threadIdx.x; k4 < K / 4; k4 += 256) {
-        const float4* src = reinterpret_cast<const float4*>(it.slab) + (size_t)co * (K / 4) + k4;
-        const float4 z = {0.f, 0.f, 0.f, 0.f};
-        float4 s0 = z, s1 = z, s2 = z, s3 = z;
-        if (chunk == 1) {
-            int sp = 0;
-            for (; sp + 3 < splits; sp += 4) {
-                add4(s0, src[(size_t)sp * total4]); add4(s1, src[(size_t)(sp + 1) * total4]);
-                add4(s2, src[(size_t)(sp + 2) * total4]); add4(s3, src[(size_t)(sp + 3) * total4]);
+    float* o = it.dw + (size_t)co * cin_real * KHW;
+    for (int ci0 = 0; ci0 < Cin_pad; ci0 += CB) {
+        const int cb = min(CB, Cin_pad - ci0), cb4 = cb / 4;
+        for (int q = threadIdx.x; q < KHW * cb4; q += 256) {
+            const int tap = q / cb4, c4 = q - tap * cb4;
+            const float4* src = reinterpret_cast<const float4*>(it.slab) + (size_t)co * (K / 4) + (tap * Cin_pad + ci0) / 4 + c4;
+            const float4 z = {0.f, 0.f, 0.f, 0.f};
+            float4 s0 = z, s1 = z, s2 = z, s3 = z;
+            if (chunk == 1) {
+                int sp = 0;
+                for (; sp + 3 < splits; sp += 4) {
+                    add4(s0, src[(size_t)sp * total4]); add4(s1, src[(size_t)(sp + 1) * total4]);
+                    add4(s2, src[(size_t)(sp + 2) * total4]); add4(s3, src[(size_t)(sp + 3) * total4]);
+                }
+                for (; sp < splits; ++sp) add4(s0, src[(size_t)sp * total4]);
+            } else {
+                auto part = [&](int ro) {
+                    const int r0 = ro * chunk, r1 = min(splits, r0 + chunk);
+                    float4 a = z, c = z;
+                    int r = r0;
+                    for (; r + 1 < r1; r += 2) { add4(a, src[(size_t)r * total4]); add4(c, src[(size_t)(r + 1) * total4]); }
+                    if (r < r1) add4(a, src[(size_t)r * total4]);
+                    add4(a, c);
+                    return a;
+                };
+                const int rows = (splits + chunk - 1) / chunk;
+                int ro = 0;
+                for (; ro + 3 < rows; ro += 4) { add4(s0, part(ro)); add4(s1, part(ro + 1)); add4(s2, part(ro + 2)); add4(s3, part(ro + 3)); }
+                for (; ro < rows; ++ro) add4(s0, part(ro));
             }
-            for (; sp < splits; ++sp) add4(s0, src[(size_t)sp * total4]);
-        } else {
-            auto part = [&](int ro) {
-                const int r0 = ro * chunk, r1 = min(splits, r0 + chunk);
-                float4 a = z, c = z;
-                int r = r0;
-                for (; r + 1 < r1; r += 2) { add4(a, src[(size_t)r * total4]); add4(c, src[(size_t)(r + 1) * total4]); }
-                if (r < r1) add4(a, src[(size_t)r * total4]);
-                add4(a, c);
-                return a;
-            };
-            const int rows = (splits + chunk - 1) / chunk;
-            int ro = 0;
-            for (; ro + 3 < rows; ro += 4) { add4(s0, part(ro)); add4(s1, part(ro + 1)); add4(s2, part(ro + 2)); add4(s3, part(ro + 3)); }
-            for (; ro < rows; ++ro) add4(s0, part(ro));
+            add4(s0, s1); add4(s2, s3); add4(s0, s2);
+            reinterpret_cast<float4*>(sk)[q] = s0;                 // sk[tap][c4*4 ..]
         }
-        add4(s0, s1); add4(s2, s3); add4(s0, s2);
-        reinterpret_cast<float4*>(sk)[k4] = s0;
-    }
-    __syncthreads();
-    const int cin_real = it.Cin_real & 0x7fff, accumulate = it.Cin_real >> 15;
-    const int nn = cin_real * KHW;
-    float* o = it.dw + (size_t)co * nn;
-    for (int j = threadIdx.x; j < nn; j += 256) {
-        const int ci = j / KHW, tap = j - ci * KHW;
-        const float v = sk[tap * Cin_pad + ci];
-        o[j] = accumulate ? o[j] + v : v;
+        __syncthreads();
+        const int creal = min(cb, cin_real - ci0);                  // real channels of this chunk (<= 0: padding only)
+        for (int j = threadIdx.x; j < creal * KHW; j += 256) {
+            const int ci = j / KHW, tap = j - ci * KHW;
+            const float v = sk[tap * cb + ci];
+            float* dst = o + (size_t)(ci0 + ci) * KHW + tap;
+            *dst = accumulate ? *dst + v : v;
+        }
+        __syncthreads();
     }
 }
 
@@ -1278,9 +1245,8 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     return (int)want;
 }
 
-// GEMM + (for tall slab stacks) fold.  On return *red_src / *red_rows say where the <= SDE_WGRAD_FOLD_ROWS (or `splits`) slabs to sum are.
-static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, hipStream_t s, Gather& g,
-                         const float** red_src, int* red_rows, bool fold) {
+// The GEMM: `splits` fp32 slabs [Cout][Ktot].
+static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, hipStream_t s, Gather& g) {
     WGradP p;
     int rc = fill_gather(d, p.g, "sde_conv_wgrad");
     if (rc) return rc;
@@ -1295,28 +1261,41 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     if (d->dtype == SDE_BF16) dispatch_wgrad<bf16_t>(p, splits, s);
     else dispatch_wgrad<float>(p, splits, s);
     SDE_CHECK_LAUNCH("sde_conv_wgrad");
-    SDE_CHECK_ARG((size_t)p.g.Ktot * sizeof(float) <= 160 * 1024, "sde_conv_wgrad: K=%d too large for the reduce kernel's LDS transpose", p.g.Ktot);
-    *red_src = slab; *red_rows = splits;
-    if (fold && splits > SDE_WGRAD_FOLD_ROWS) {     // fold into the SDE_WGRAD_FOLD_ROWS scratch rows behind the slab stack
-        const size_t width4 = (size_t)Cout * p.g.Ktot / 4;      // Ktot is a multiple of 4 elements
-        const int chunk = sde_cdiv(splits, SDE_WGRAD_FOLD_ROWS);
-        *red_rows = sde_cdiv(splits, chunk);
-        float* scratch = slab + (size_t)splits * Cout * p.g.Ktot;
-        hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((width4 + 255) / 256), *red_rows), dim3(256), 0, s, slab, splits, width4, chunk, scratch);
-        SDE_CHECK_LAUNCH("sde_conv_wgrad/fold");
-        *red_src = scratch;
-    }
     g = p.g;
     return SDE_OK;
 }
 
-static void set_reduce_lds_attr() {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        done = true;
+static int launch_wreduce(const sde_wreduce_item* items, int n, hipStream_t s) {
+    for (int i = 0; i < n; ++i) {
+        const sde_wreduce_item& it = items[i];
+        SDE_CHECK_ARG(it.slab && it.dw && it.rows >= 1 && it.rows <= 65535 && it.Cout >= 1 && it.Cout <= 65535 && it.KHW >= 1 && it.KHW <= 4096 &&
+                          it.Cin_pad >= 4 && it.Cin_pad <= 32767 && it.Cin_pad % 4 == 0 && it.Cin_real >= 1 && it.Cin_real <= it.Cin_pad,
+                      "sde_wgrad_reduce_batched: item %d out of range", i);
+        SDE_CHECK_ARG(((uintptr_t)it.slab & 15) == 0, "sde_wgrad_reduce_batched: item %d: unaligned slab", i);
     }
+    for (int i0 = 0; i0 < n; i0 += WREDUCE_MAX) {
+        WReduceBatch batch;
+        batch.n = n - i0 < WREDUCE_MAX ? n - i0 : WREDUCE_MAX; batch.lds_floats = WREDUCE_LDS_FLOATS;
+        int end = 0, need = 0;
+        for (int i = 0; i < batch.n; ++i) {
+            const sde_wreduce_item& it = items[i0 + i];
+            end += it.Cout;
+            const int lds = it.KHW * wreduce_cb(it.KHW, it.Cin_pad, WREDUCE_LDS_FLOATS);
+            if (lds > need) need = lds;
+            const int chunk = it.rows > SDE_WGRAD_FOLD_ROWS ? sde_cdiv(it.rows, SDE_WGRAD_FOLD_ROWS) : 1;
+            batch.it[i] = WReduceArg{it.slab, it.dw, end, (unsigned short)it.rows, (unsigned short)chunk, (unsigned short)it.Cout, (unsigned short)it.KHW,
+                                     (unsigned short)it.Cin_pad, (unsigned short)(it.Cin_real | (it.accumulate ? 0x8000 : 0))};
+        }
+        for (int i = batch.n; i < WREDUCE_MAX; ++i) batch.it[i] = WReduceArg{nullptr, nullptr, end, 0, 0, 0, 0, 0, 0};
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)end), dim3(256), (size_t)need * sizeof(float), s, batch);
+        SDE_CHECK_LAUNCH("sde_wgrad_reduce_batched");
+    }
+    return SDE_OK;
 }
 
 int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, int Cin_real, float* slab, int splits, float* dw,
@@ -1324,52 +1303,22 @@ int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, in
     SDE_CHECK_ARG(d && dy && slab && dw, "sde_conv_wgrad: null pointer");
     hipStream_t s = (hipStream_t)stream;
     Gather g;
-    const float* red_src; int red_rows;
-    int rc = wgrad_partial(d, dy, Cout, ldd, slab, splits, s, g, &red_src, &red_rows, true);
+    int rc = wgrad_partial(d, dy, Cout, ldd, slab, splits, s, g);
     if (rc) return rc;
     SDE_CHECK_ARG(Cin_real >= 1 && Cin_real <= g.Cin, "sde_conv_wgrad: bad Cin_real=%d", Cin_real);
-    set_reduce_lds_attr();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(Cout), dim3(256), (size_t)g.Ktot * sizeof(float), s, red_src, red_rows, Cout, d->KH * d->KW, g.Cin, Cin_real, dw,
-                       accumulate);
-    SDE_CHECK_LAUNCH("sde_conv_wgrad/reduce");
-    return SDE_OK;
+    const sde_wreduce_item it = {slab, dw, splits, Cout, d->KH * d->KW, g.Cin, Cin_real, accumulate};
+    return launch_wreduce(&it, 1, s);
 }
 
 int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, sde_stream_t stream) {
     SDE_CHECK_ARG(d && dy && slab, "sde_conv_wgrad_partial: null pointer");
     Gather g;
-    const float* src; int rows;
-    return wgrad_partial(d, dy, Cout, ldd, slab, splits, (hipStream_t)stream, g, &src, &rows, false);
+    return wgrad_partial(d, dy, Cout, ldd, slab, splits, (hipStream_t)stream, g);
 }
 
 int sde_wgrad_reduce_batched(const sde_wreduce_item* items, int n, sde_stream_t stream) {
     SDE_CHECK_ARG(items && n > 0, "sde_wgrad_reduce_batched: bad argument");
-    set_reduce_lds_attr();
-    for (int i = 0; i < n; ++i) {
-        const sde_wreduce_item& it = items[i];
-        SDE_CHECK_ARG(it.slab && it.dw && it.rows >= 1 && it.rows <= 65535 && it.Cout >= 1 && it.Cout <= 65535 && it.KHW >= 1 && it.KHW <= 65535 &&
-                          it.Cin_pad >= 1 && it.Cin_pad <= 32767 && it.Cin_real >= 1 && it.Cin_real <= it.Cin_pad,
-                      "sde_wgrad_reduce_batched: item %d out of range", i);
-        SDE_CHECK_ARG((size_t)it.KHW * it.Cin_pad * sizeof(float) <= 160 * 1024, "sde_wgrad_reduce_batched: item %d: K too large", i);
-        SDE_CHECK_ARG((it.KHW * it.Cin_pad) % 4 == 0 && ((uintptr_t)it.slab & 15) == 0, "sde_wgrad_reduce_batched: item %d: K %% 4 != 0 or unaligned slab", i);
-    }
-    for (int i0 = 0; i0 < n; i0 += WREDUCE_MAX) {
-        WReduceBatch batch;
-        batch.n = n - i0 < WREDUCE_MAX ? n - i0 : WREDUCE_MAX; batch.pad = 0;
-        int end = 0, max_k = 0;
-        for (int i = 0; i < batch.n; ++i) {
-            const sde_wreduce_item& it = items[i0 + i];
-            end += it.Cout;
-            if (it.KHW * it.Cin_pad > max_k) max_k = it.KHW * it.Cin_pad;
-            const int chunk = it.rows > SDE_WGRAD_FOLD_ROWS ? sde_cdiv(it.rows, SDE_WGRAD_FOLD_ROWS) : 1;     // as sde_conv_wgrad folds
-            batch.it[i] = WReduceArg{it.slab, it.dw, end, (unsigned short)it.rows, (unsigned short)chunk, (unsigned short)it.Cout, (unsigned short)it.KHW,
-                                     (unsigned short)it.Cin_pad, (unsigned short)(it.Cin_real | (it.accumulate ? 0x8000 : 0))};
-        }
-        for (int i = batch.n; i < WREDUCE_MAX; ++i) batch.it[i] = WReduceArg{nullptr, nullptr, end, 0, 0, 0, 0, 0, 0};
-        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)end), dim3(256), (size_t)max_k * sizeof(float), (hipStream_t)stream, batch);
-        SDE_CHECK_LAUNCH("sde_wgrad_reduce_batched");
-    }
-    return SDE_OK;
+    return launch_wreduce(items, n, (hipStream_t)stream);
 }
 
 int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cin_pad, int Cout_pad, int for_dgrad,

@@ -551,6 +551,13 @@ __global__ void __launch_bounds__(256) depth_head_bwd_kernel(const T* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int GN_CHUNKS = 16;
 
+// activation fused behind the normalisation: 0 none, 1 ReLU (PoseNet.py:L13-20), 2 ELU (layers01.py:L33-40); the derivative is taken
+// from the stored output, as the reference's in-place activations do
+__device__ __forceinline__ float gn_act(float v, int act) { return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : expm1f(v)) : v); }
+__device__ __forceinline__ float gn_act_grad(float d, float out, int act) {
+    return act == 1 ? (out > 0.f ? d : 0.f) : (act == 2 ? (out > 0.f ? d : d * (out + 1.0f)) : d);
+}
+
 // The 256/C threads that walked channel c = tid % C combine their partial sums in thread order (no float atomics: the statistics,
 // and with them every PoseNet gradient, are bit-reproducible from run to run).  All 256 threads must call it; sh = [2][C].
 __device__ __forceinline__ void fixed_order_channel_sum(float a1, float a2, int C, float* sh) {
@@ -620,8 +627,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
         const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
         const float* st = gnp + ((size_t)b * G + c / cpg) * 2;
         float v = ((float)x[i] - st[0]) * st[1] * gamma[c] + beta[c];
-        if (relu) v = fmaxf(v, 0.f);
-        out[i] = (T)v;
+        out[i] = (T)gn_act(v, relu);
     }
 }
 
@@ -644,7 +650,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
         float a1 = 0.f, a2 = 0.f;
         for (long i = threadIdx.x; i < total; i += 256) {
             float d = (float)dout[base + i];
-            if (relu && !((float)out[base + i] > 0.f)) d = 0.f;
+            if (relu) d = gn_act_grad(d, (float)out[base + i], relu);
             const float xh = ((float)x[base + i] - st[0]) * st[1];
             a1 += d; a2 += d * xh;
         }
@@ -654,7 +660,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
             const int c = (int)(i % C);
             const float* st = gnp + ((size_t)b * G + c / cpg) * 2;
             float d = (float)dout[base + i];
-            if (relu && !((float)out[base + i] > 0.f)) d = 0.f;
+            if (relu) d = gn_act_grad(d, (float)out[base + i], relu);
             const float xh = ((float)x[base + i] - st[0]) * st[1];
             atomicAdd(&sh[c], d); atomicAdd(&sh[C + c], d * xh);
         }
@@ -703,7 +709,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
         const size_t gi = ((size_t)b * G + c / cpg) * 2;
         float d = (float)dout[i];
-        if (relu && !((float)out[i] > 0.f)) d = 0.f;
+        if (relu) d = gn_act_grad(d, (float)out[i], relu);
         const float xh = ((float)x[i] - gnp[gi]) * gnp[gi + 1];
         dx[i] = (T)(gnp[gi + 1] * (gamma[c] * d - coef[gi] - xh * coef[gi + 1]));
     }

@@ -48,6 +48,10 @@ L.register_protos({
     "sde_depth_head_bwd": ([_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P], c_int),
     "sde_gn_relu_fwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P], c_int),
     "sde_gn_relu_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P], c_int),
+    "sde_conv3d_fwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
+    "sde_conv3d_dgrad": ([_P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
+    "sde_conv3d_wgrad_num_blocks": ([_I, _I, _I, _I, _I], c_int),
+    "sde_conv3d_wgrad": ([_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], c_int),
     "sde_adam_step": ([_P, _P, _P, _P, _LG, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _I, _P], c_int),
 })
 
@@ -225,8 +229,7 @@ class _Conv2d(torch.autograd.Function):
                 wctx = contextlib.nullcontext()
             dw = wslot if wslot is not None else torch.empty_like(weight)
             defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and WGRAD_DEFER.accepts(wslot)) else None
-            # immediate reduction folds tall stacks into FOLD_ROWS scratch rows behind the slabs; the deferred one needs no scratch
-            slab = torch.empty(splits + (FOLD_ROWS if (defer is None and splits > FOLD_ROWS) else 0), Cout, KH * KW * (C0 + C1), device=dev)
+            slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
             with wctx:
                 if defer is not None:
                     _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits, L.stream()),
@@ -533,10 +536,59 @@ class _GroupNormReLU(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None
 
 
+GN_ACT = {False: 0, True: 1, "none": 0, "relu": 1, "elu": 2}
+
+
 def group_norm_relu(x, gamma, beta, groups=16, eps=1e-5, relu=True):
+    """GroupNorm + activation; relu: True / "relu" (PoseNet.py:L13-20), "elu" (layers01.py:L33-40), False / "none"."""
     if x.shape[-1] != gamma.numel():
-        raise L.SdeHipError("group_norm_relu: channel padding is not supported (PoseNet channels are multiples of 16)")
-    return _GroupNormReLU.apply(x, gamma, beta, int(groups), float(eps), bool(relu))
+        raise L.SdeHipError("group_norm_relu: channel padding is not supported (PoseNet / PackNet channels are multiples of 16)")
+    return _GroupNormReLU.apply(x, gamma, beta, int(groups), float(eps), GN_ACT[relu])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PackNet's Conv3d(1, 8, 3, padding=1) over the (channel, y, x) volume (layers01.py:L223-298)
+# ---------------------------------------------------------------------------------------------------------------
+class _Conv3dPack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, H, W, D = x.shape
+        lib = L.lib()
+        x = x.contiguous()
+        y = torch.empty(B, H, W, 8 * D, device=x.device, dtype=x.dtype)
+        L.check(lib.sde_conv3d_fwd(L.ptr(x), L.ptr(_f32(weight)), L.ptr(_f32(bias)), B, H, W, D, dtype_code(x.dtype), L.ptr(y), L.stream()), "sde_conv3d_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.params = (weight, bias)
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        x, weight = ctx.saved_tensors
+        B, H, W, D = x.shape
+        lib = L.lib()
+        dy = dy.contiguous()
+        dc = dtype_code(x.dtype)
+        ws, bs = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+        direct = ws is not None and bs is not None
+        dw = ws if direct else torch.empty_like(weight)
+        db = bs if direct else torch.empty(8, device=x.device)
+        part = torch.empty(lib.sde_conv3d_wgrad_num_blocks(B, H, W, D, dc), 224, device=x.device)
+        L.check(lib.sde_conv3d_wgrad(L.ptr(x), L.ptr(dy), B, H, W, D, dc, L.ptr(part), L.ptr(dw), L.ptr(db), int(direct), L.stream()), "sde_conv3d_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.check(lib.sde_conv3d_dgrad(L.ptr(dy), L.ptr(_f32(weight)), B, H, W, D, dc, L.ptr(dx), L.stream()), "sde_conv3d_dgrad")
+        return dx, (None if direct else dw), (None if direct else db)
+
+
+def conv3d_pack(x, weight, bias):
+    """x: NHWC [B,H,W,D]; weight [8,1,3,3,3] fp32; bias [8] -> [B,H,W,8*D] (channel = feature*D + ch, as view(b, c*d, h, w))."""
+    if tuple(weight.shape) != (8, 1, 3, 3, 3):
+        raise L.SdeHipError(f"conv3d_pack: weight shape {tuple(weight.shape)} (expected [8,1,3,3,3])")
+    return _Conv3dPack.apply(x, weight, bias)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -60,6 +60,12 @@ CONV_CASES = [
     ("k7_s2_pose_in9", 2, 32, 64, 9, 16, 7, 2, 3, False, True, 0),
     ("3x3_bigM_64_128", 2, 96, 160, 64, 128, 3, 1, 1, False, False, 0),
     ("3x3_s2_odd", 1, 13, 21, 32, 32, 3, 2, 1, False, True, 0),
+    # PackNet01 shapes (layers01.py): huge K after the 3-D convolution (weight-gradient transpose in channel chunks), 5x5 / 7x7 stride 1,
+    # concatenated inputs with an odd channel count (193 = 128 + 64 + 1 inverse-depth channel)
+    ("3x3_2048_64_bigK", 1, 6, 10, 2048, 64, 3, 1, 1, False, True, 0),
+    ("5x5_1024_64_pack", 1, 8, 12, 1024, 64, 5, 1, 2, False, True, 0),
+    ("7x7_s1_64_64", 1, 12, 20, 64, 64, 7, 1, 3, False, True, 0),
+    ("3x3_193_128_cat", 1, 8, 12, 193, 128, 3, 1, 1, False, True, 0),
 ]
 
 
@@ -250,6 +256,59 @@ def test_group_norm_relu(NN, dtype, C, H, W):
     check(nchw(xd.grad, C), xr.grad, dtype, "gn dx", 5e-5, 3e-2)
     check(gd.grad.cpu(), gr.grad, dtype, "gn dgamma", 5e-5, 3e-2)
     check(bd.grad.cpu(), br.grad, dtype, "gn dbeta", 5e-5, 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,H,W", [(64, 12, 20), (512, 6, 10)])
+def test_group_norm_elu(NN, dtype, C, H, W):
+    """PackNet's Conv2D tail: GroupNorm(16) + ELU (layers01.py:L33-40)."""
+    g = torch.Generator().manual_seed(C + H + 1)
+    V = 4 if dtype == torch.float32 else 8
+    B = 2
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.3
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.3
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gamma, beta))
+    o = F.elu(F.group_norm(xr, 16, gr, br, 1e-5))
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    xd = nhwc(x, dtype, V).requires_grad_(True)
+    gd, bd = (t.clone().to(dev).requires_grad_(True) for t in (gamma, beta))
+    out = NN.group_norm_relu(xd, gd, bd, 16, 1e-5, "elu")
+    check(nchw(out, C), o.detach(), dtype, "gn-elu out")
+    out.backward(nhwc(go, dtype, V))
+    check(nchw(xd.grad, C), xr.grad, dtype, "gn-elu dx", 5e-5, 3e-2)
+    check(gd.grad.cpu(), gr.grad, dtype, "gn-elu dgamma", 5e-5, 3e-2)
+    check(bd.grad.cpu(), br.grad, dtype, "gn-elu dbeta", 5e-5, 3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,D,H,W", [(2, 16, 5, 7), (1, 64, 9, 12), (2, 256, 3, 4)])
+def test_conv3d_pack(NN, dtype, B, D, H, W):
+    """layers01.py:L223-298: x.unsqueeze(1) -> Conv3d(1, 8, 3, padding=1) -> view(b, 8*D, h, w), forward and all three gradients."""
+    g = torch.Generator().manual_seed(D + H)
+    x = torch.randn(B, D, H, W, generator=g)
+    w = torch.randn(8, 1, 3, 3, 3, generator=g) * 0.3
+    bias = torch.randn(8, generator=g) * 0.2
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, bias))
+    o = F.conv3d(xr.unsqueeze(1), wr, br, padding=1).reshape(B, 8 * D, H, W)
+    go = torch.randn(o.shape, generator=g)
+    if dtype == torch.bfloat16:
+        go = go.bfloat16().float()
+    o.backward(go)
+    V = 4 if dtype == torch.float32 else 8
+    xd = nhwc(x, dtype, V).requires_grad_(True)
+    wd, bd = (t.clone().to(dev).requires_grad_(True) for t in (w, bias))
+    out = NN.conv3d_pack(xd, wd, bd)
+    assert out.shape == (B, H, W, 8 * D)
+    check(nchw(out, 8 * D), o.detach(), dtype, "conv3d out")
+    out.backward(nhwc(go, dtype, V))
+    check(nchw(xd.grad, D), xr.grad, dtype, "conv3d dx")
+    check(wd.grad.cpu(), wr.grad, dtype, "conv3d dw", 2e-5, 2e-5)       # gradients are accumulated in fp32 from the same rounded operands
+    check(bd.grad.cpu(), br.grad, dtype, "conv3d dbias", 2e-5, 2e-5)
 
 
 def test_prep_input(NN):
