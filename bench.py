@@ -34,6 +34,7 @@ WORKLOADS = {
     "sup_r18": dict(arch="SupDepthModel", enc="18", desc="Supervised ResNet-18"),
     "mono_r18": dict(arch="MonoDepth2Model", enc="18", desc="MonoDepth2 ResNet-18 3-frame (BASELINE configs[2])"),
     "mono_r50": dict(arch="MonoDepth2Model", enc="50", desc="MonoDepth2 ResNet-50 3-frame (BASELINE configs[3])"),
+    "mono_packnet": dict(arch="MonoDepth2Model", enc="18", packnet="1A", desc="MonoDepth2 PackNet-1A 3-frame (BASELINE configs[4], bf16 instead of fp16)"),
 }
 
 
@@ -62,6 +63,8 @@ def build(args, device):
     cfg.MODEL.COMPUTE_DTYPE = args.dtype
     cfg.MODEL.DEVICE = str(device)
     cfg.SOLVER.DEPTH_LR = 1e-4 if wl["arch"] == "SupDepthModel" else 2e-4
+    if wl.get("packnet"):                           # projects/MonoDepth2/configs/packnet_1a.yaml
+        cfg.MODEL.DEPTH_NET.NAME, cfg.MODEL.DEPTH_NET.VERSION, cfg.LOSS.VAR_LOSS_WEIGHT = "PackNet01", wl["packnet"], 1e-4
     torch.manual_seed(0)
     model = build_model(cfg).train()
     mk = T.supervised_trainer if wl["arch"] == "SupDepthModel" else T.monodepth2_trainer
@@ -138,7 +141,10 @@ def cpu_baseline(args):
     enc = int(wl["enc"])
     B, H, W = args.cpu_batch, args.height, args.width
     threads = torch.get_num_threads()
-    sd = OM.init_state_dict(enc, with_pose=wl["arch"] != "SupDepthModel", seed=0)
+    if wl.get("packnet"):
+        sd, enc = OM.init_packnet_state_dict(wl["packnet"][-1], seed=0), "packnet" + wl["packnet"]
+    else:
+        sd = OM.init_state_dict(enc, with_pose=wl["arch"] != "SupDepthModel", seed=0)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k and "pixel" not in k and ".fc." not in k}
     state = dict(sd); state.update(leaves)
     opt = torch.optim.AdamW(list(leaves.values()), lr=1e-4, eps=1e-6) if wl["arch"] == "SupDepthModel" else torch.optim.Adam(list(leaves.values()), lr=2e-4)
@@ -150,8 +156,8 @@ def cpu_baseline(args):
             out = OM.supervised_forward(state, batch, enc, update_running=True)
             loss = out["silog_loss"]
         else:
-            out = OM.monodepth2_forward(state, batch, enc, update_running=True)
-            loss = out["rec_loss"] + out["smooth_loss"]
+            out = OM.monodepth2_forward(state, batch, enc, update_running=True, **({"var_w": 1e-4} if wl.get("packnet") else {}))
+            loss = out["rec_loss"] + out["smooth_loss"] + out.get("var_loss", 0.0)
         loss.backward()
         opt.step()
     step()

@@ -213,12 +213,49 @@ def gen_models(ref):
     print("models.npz", len(res), "arrays")
 
 
+PROBE_PARAMS_PACKNET = ["depth_net.pre_calc.conv_base.weight", "depth_net.pack1.conv3d.weight", "depth_net.pack1.conv3d.bias",
+                        "depth_net.pack1.conv.conv_base.weight", "depth_net.conv3.1.conv3.weight", "depth_net.conv5.2.normalize.weight",
+                        "depth_net.pack5.conv.conv_base.weight", "depth_net.unpack5.conv3d.weight", "depth_net.unpack3.conv.conv_base.bias",
+                        "depth_net.iconv3.conv_base.weight", "depth_net.iconv1.normalize.bias", "depth_net.disp2_layer.conv1.weight",
+                        "pose_net.conv1.0.weight"]
+
+
+def gen_packnet(ref):
+    """MonoDepth2Model + PackNet01 (config 5 of BASELINE.json: packnet_1a.yaml, VAR_LOSS_WEIGHT 1e-4), B=1, 64x192, CPU fp32."""
+    res = {}
+    for tag, version in [("packnet1A", "A"), ("packnet1B", "B")]:
+        sd = OM.init_packnet_state_dict(version, seed=5)
+        model = ref.MonoDepth2Fixed(ref_harness.make_cfg("MonoDepth2Model", depth_net="PackNet01", version="1" + version, VAR_LOSS_WEIGHT=1e-4))
+        load_ref_weights(model, sd)
+        model.train()
+        batch = mono_batch(1, 64, 192, 21)
+        out = model({k: ([x.clone() for x in v] if isinstance(v, list) else v.clone()) for k, v in batch.items()})
+        (out["rec_loss"] + out["smooth_loss"] + out["var_loss"]).backward()
+        for k in ("rec_loss", "smooth_loss", "var_loss"):
+            res[f"{tag}.{k}"] = np.float64(out[k].item())
+        for n, v in grad_norms(model, PROBE_PARAMS_PACKNET).items():
+            res[f"{tag}.gnorm.{n}"] = np.float64(v)
+        model.eval()
+        with torch.no_grad():
+            b2 = {k: ([x.clone() for x in v] if isinstance(v, list) else v.clone()) for k, v in batch.items()}
+            b2["depth_net_input"] = (b2["img"] - model.pixel_mean) / model.pixel_std
+            depths = model.depth_net(b2)["depth_pred"]
+            for i, d in enumerate(depths):
+                res[f"{tag}.depth{i}"] = np_(d)
+            fb = dict(b2); fb["flip"] = True
+            res[f"{tag}.flip_depth0"] = np_(model.depth_net(fb)["depth_pred"][0])
+    np.savez_compressed(os.path.join(OUT, "packnet.npz"), **res)
+    print("packnet.npz", len(res), "arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_harness.load()
-    gen_geometry(ref)
-    gen_models(ref)
+    if "--packnet-only" not in sys.argv:
+        gen_geometry(ref)
+        gen_models(ref)
+    gen_packnet(ref)
 
 
 if __name__ == "__main__":

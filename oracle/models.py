@@ -93,6 +93,47 @@ def init_state_dict(num_layers, with_pose=False, num_ctx=2, seed=0):
     return sd
 
 
+def init_packnet_state_dict(version="A", with_pose=True, num_ctx=2, seed=0):
+    """PackNet01 (+ PoseNet) parameters with the reference's names and initialisers: xavier-uniform Conv2d / Conv3d weights, zero
+    biases (PackNet01.py:L110-116), GroupNorm gamma=1 beta=0."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    p = "depth_net."
+
+    def xavier(name, shape):
+        rf = 1
+        for s_ in shape[2:]:
+            rf *= s_
+        a = math.sqrt(6.0 / (shape[1] * rf + shape[0] * rf))
+        sd[name + ".weight"] = (torch.rand(*shape, generator=g) * 2 - 1) * a
+        sd[name + ".bias"] = torch.zeros(shape[0])
+
+    def gn(name, c):
+        sd[name + ".weight"] = torch.ones(c); sd[name + ".bias"] = torch.zeros(c)
+
+    def conv2d(name, ci, co, k):
+        xavier(name + ".conv_base", (co, ci, k, k)); gn(name + ".normalize", co)
+
+    for name, kind, a in N.packnet_layout(version):
+        if kind == "conv2d":
+            conv2d(p + name, a[0], a[1], a[2])
+        elif kind == "pack":
+            conv2d(p + name + ".conv", a[0] * 4 * 8, a[0], a[1]); xavier(p + name + ".conv3d", (8, 1, 3, 3, 3))
+        elif kind == "unpack":
+            conv2d(p + name + ".conv", a[0], a[1] * 4 // 8, a[2]); xavier(p + name + ".conv3d", (8, 1, 3, 3, 3))
+        elif kind == "res":
+            conv2d(p + name + ".conv1", a[0], a[1], 3); conv2d(p + name + ".conv2", a[1], a[1], 3)
+            xavier(p + name + ".conv3", (a[1], a[0], 1, 1)); gn(p + name + ".normalize", a[1])
+        else:
+            xavier(p + name + ".conv1", (1, a[0], 3, 3))
+    if with_pose:
+        pose = init_state_dict(18, with_pose=True, num_ctx=num_ctx, seed=seed + 1)
+        sd.update({k: v for k, v in pose.items() if k.startswith("pose_net.")})
+    sd["pixel_mean"] = torch.tensor(PIXEL_MEAN).view(1, 3, 1, 1)
+    sd["pixel_std"] = torch.tensor(PIXEL_STD).view(1, 3, 1, 1)
+    return sd
+
+
 def normalise(sd, img):
     return (img - sd["pixel_mean"]) / sd["pixel_std"]
 
@@ -151,9 +192,12 @@ def monodepth2_losses(depths, poses, image, contexts, intrinsics, ssim_w=0.85, C
 
 
 def monodepth2_forward(sd, batch, num_layers, max_depth=80.0, training=True, update_running=False, **loss_kw):
-    """MonoDepth2.py:L55-128."""
+    """MonoDepth2.py:L55-128.  num_layers: 18 / 34 / 50 (DepthResNet) or "packnet1A" / "packnet1B" (PackNet01)."""
     x = normalise(sd, batch["img"])
-    depths, _ = N.depth_resnet(sd, x, num_layers, max_depth, bool(batch.get("flip", False)), training, update_running)
+    if isinstance(num_layers, str) and num_layers.startswith("packnet"):
+        depths = N.packnet01(sd, x, num_layers[-1], max_depth, bool(batch.get("flip", False)))
+    else:
+        depths, _ = N.depth_resnet(sd, x, num_layers, max_depth, bool(batch.get("flip", False)), training, update_running)
     if not training:
         return {"depth_pred": depths[0]}
     pin = torch.cat([batch["img"]] + list(batch["ctx_img"]), 1)

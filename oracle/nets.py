@@ -156,3 +156,117 @@ def pose_net(sd, x, num_ctx=2, prefix="pose_net."):
     p = F.conv2d(x, sd[prefix + "pose_pred.weight"], sd[prefix + "pose_pred.bias"])
     p = p.mean(3).mean(2)
     return 0.01 * p.view(p.size(0), num_ctx, 6)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# PackNet01 (reference: modeling/depth_net/PackNet01.py:L18-209 + layers/layers01.py:L11-298), version "A" / "B"
+# ------------------------------------------------------------------------------------------------------------------
+def packnet_layout(version="A"):
+    """(module path, kind, args) for every parameterised layer, in the reference's construction order.
+    kinds: conv2d (Conv2D: conv_base + GroupNorm), res (ResidualConv), pack / unpack (… + conv3d), inv (InvDepth)."""
+    ni, no = 64, 1
+    n1, n2, n3, n4, n5 = 64, 64, 128, 256, 512
+    if version == "A":
+        n1o, n1i = n1, n1 + ni + no
+        n2o, n2i = n2, n2 + n1 + no
+        n3o, n3i = n3, n3 + n2 + no
+        n4o, n4i = n4, n4 + n3
+        n5o, n5i = n5, n5 + n4
+    else:
+        n1o, n1i = n1, n1 + no
+        n2o, n2i = n2, n2 + no
+        n3o, n3i = n3 // 2, n3 // 2 + no
+        n4o, n4i = n4 // 2, n4 // 2
+        n5o, n5i = n5 // 2, n5 // 2
+    L = [("pre_calc", "conv2d", (3, ni, 5))]
+    for name, c, k in [("pack1", n1, 5), ("pack2", n2, 3), ("pack3", n3, 3), ("pack4", n4, 3), ("pack5", n5, 3)]:
+        L.append((name, "pack", (c, k)))
+    L.append(("conv1", "conv2d", (ni, n1, 7)))
+    for name, ci, co, nb in [("conv2", n1, n2, 2), ("conv3", n2, n3, 2), ("conv4", n3, n4, 3), ("conv5", n4, n5, 3)]:
+        for b in range(nb):
+            L.append((f"{name}.{b}", "res", (ci if b == 0 else co, co)))
+    for name, ci, co in [("unpack5", n5, n5o), ("unpack4", n5, n4o), ("unpack3", n4, n3o), ("unpack2", n3, n2o), ("unpack1", n2, n1o)]:
+        L.append((name, "unpack", (ci, co, 3)))
+    for name, ci, co in [("iconv5", n5i, n5), ("iconv4", n4i, n4), ("iconv3", n3i, n3), ("iconv2", n2i, n2), ("iconv1", n1i, n1)]:
+        L.append((name, "conv2d", (ci, co, 3)))
+    for name, ci in [("disp4_layer", n4), ("disp3_layer", n3), ("disp2_layer", n2), ("disp1_layer", n1)]:
+        L.append((name, "inv", (ci,)))
+    return L
+
+
+def _pn_conv2d(sd, p, x):
+    """layers01.Conv2D: ConstantPad2d(k//2) + Conv2d + GroupNorm(16) + ELU."""
+    w = sd[p + ".conv_base.weight"]
+    x = F.conv2d(x, w, sd[p + ".conv_base.bias"], 1, w.shape[-1] // 2)
+    return F.elu(F.group_norm(x, 16, sd[p + ".normalize.weight"], sd[p + ".normalize.bias"], 1e-5))
+
+
+def _pn_res(sd, p, x):
+    out = _pn_conv2d(sd, p + ".conv2", _pn_conv2d(sd, p + ".conv1", x))
+    sc = F.conv2d(x, sd[p + ".conv3.weight"], sd[p + ".conv3.bias"])
+    return F.elu(F.group_norm(out + sc, 16, sd[p + ".normalize.weight"], sd[p + ".normalize.bias"], 1e-5))
+
+
+def packing(x, r=2):
+    """layers01.py:L138-160."""
+    b, c, h, w = x.shape
+    x = x.contiguous().view(b, c, h // r, r, w // r, r)
+    return x.permute(0, 1, 3, 5, 2, 4).contiguous().view(b, c * r * r, h // r, w // r)
+
+
+def _pn_conv3d(sd, p, x):
+    y = F.conv3d(x.unsqueeze(1), sd[p + ".conv3d.weight"], sd[p + ".conv3d.bias"], padding=1)
+    b, c, d, h, w = y.shape
+    return y.view(b, c * d, h, w)
+
+
+def _pn_pack(sd, p, x):
+    return _pn_conv2d(sd, p + ".conv", _pn_conv3d(sd, p, packing(x)))
+
+
+def _pn_unpack(sd, p, x):
+    return F.pixel_shuffle(_pn_conv3d(sd, p, _pn_conv2d(sd, p + ".conv", x)), 2)
+
+
+def _pn_inv(sd, p, x):
+    return torch.sigmoid(F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], 1, 1)) / 0.5
+
+
+def packnet01(sd, x, version="A", max_depth=80.0, flip=False, prefix="depth_net."):
+    """PackNet01.forward (PackNet01.py:L118-209) -> 4 metric depth maps (index 0 = full resolution)."""
+    q = lambda n: prefix + n   # noqa: E731
+    if flip:
+        x = torch.flip(x, [3])
+    x = _pn_conv2d(sd, q("pre_calc"), x)
+    x1 = _pn_conv2d(sd, q("conv1"), x)
+    x1p = _pn_pack(sd, q("pack1"), x1)
+
+    def block(name, n, t):
+        for b in range(n):
+            t = _pn_res(sd, q(f"{name}.{b}"), t)
+        return t
+    x2p = _pn_pack(sd, q("pack2"), block("conv2", 2, x1p))
+    x3p = _pn_pack(sd, q("pack3"), block("conv3", 2, x2p))
+    x4p = _pn_pack(sd, q("pack4"), block("conv4", 3, x3p))
+    x5p = _pn_pack(sd, q("pack5"), block("conv5", 3, x4p))
+    skip1, skip2, skip3, skip4, skip5 = x, x1p, x2p, x3p, x4p
+
+    def join(u, s, ud=None):
+        parts = [u, s] if version == "A" else [u + s]
+        if ud is not None:
+            parts.append(ud)
+        return torch.cat(parts, 1) if len(parts) > 1 else parts[0]
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")   # noqa: E731
+    iconv5 = _pn_conv2d(sd, q("iconv5"), join(_pn_unpack(sd, q("unpack5"), x5p), skip5))
+    iconv4 = _pn_conv2d(sd, q("iconv4"), join(_pn_unpack(sd, q("unpack4"), iconv5), skip4))
+    disp4 = _pn_inv(sd, q("disp4_layer"), iconv4)
+    iconv3 = _pn_conv2d(sd, q("iconv3"), join(_pn_unpack(sd, q("unpack3"), iconv4), skip3, up(disp4)))
+    disp3 = _pn_inv(sd, q("disp3_layer"), iconv3)
+    iconv2 = _pn_conv2d(sd, q("iconv2"), join(_pn_unpack(sd, q("unpack2"), iconv3), skip2, up(disp3)))
+    disp2 = _pn_inv(sd, q("disp2_layer"), iconv2)
+    iconv1 = _pn_conv2d(sd, q("iconv1"), join(_pn_unpack(sd, q("unpack1"), iconv2), skip1, up(disp2)))
+    disp1 = _pn_inv(sd, q("disp1_layer"), iconv1)
+    depths = [disp_to_depth(d, 0.1, max_depth)[1] for d in (disp1, disp2, disp3, disp4)]
+    if flip:
+        depths = [torch.flip(d, [3]) for d in depths]
+    return depths

@@ -175,6 +175,8 @@ def load():
     _loaded["resnet_encoder"] = imp("detectron2.layers.resnet_encoder")
     dn_build = imp("detectron2.modeling.depth_net.build")
     _loaded["DepthResNet"] = imp("detectron2.modeling.depth_net.DepthResNet")
+    _loaded["layers01"] = imp("detectron2.layers.layers01")
+    _loaded["PackNet01"] = imp("detectron2.modeling.depth_net.PackNet01")
     sys.modules["detectron2.modeling.depth_net"].build_depth_net = dn_build.build_depth_net
     pn_build = imp("detectron2.modeling.pose_net.build")
     _loaded["PoseNet"] = imp("detectron2.modeling.pose_net.PoseNet")
@@ -196,7 +198,7 @@ def load():
     return types.SimpleNamespace(**_loaded)
 
 
-def make_cfg(meta_arch, encoder="18", device="cpu", **loss_over):
+def make_cfg(meta_arch, encoder="18", device="cpu", depth_net="DepthResNet", version="1A", **loss_over):
     """Nested SimpleNamespace carrying exactly the cfg keys the path reads."""
     NS = types.SimpleNamespace
     loss = dict(SSIM_WEIGHT=0.85, C1=1e-4, C2=9e-4, CLIP=0.0, AUTOMASK=True, SMOOTHNESS_WEIGHT=1e-3,
@@ -204,6 +206,6 @@ def make_cfg(meta_arch, encoder="18", device="cpu", **loss_over):
     loss.update(loss_over)
     return NS(MODEL=NS(META_ARCHITECTURE=meta_arch, DEVICE=device, MAX_DEPTH=80,
                        PIXEL_MEAN=[0.485, 0.456, 0.406], PIXEL_STD=[0.229, 0.224, 0.225],
-                       DEPTH_NET=NS(NAME="DepthResNet", ENCODER_NAME=encoder, UPSAMPLE_DEPTH=False),
+                       DEPTH_NET=NS(NAME=depth_net, ENCODER_NAME=encoder, UPSAMPLE_DEPTH=False, VERSION=version),
                        POSE_NET=NS(NAME="PoseNet", NUM_CONTEXTS=2)),
               LOSS=NS(**loss))

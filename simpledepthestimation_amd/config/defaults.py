@@ -19,6 +19,7 @@ _C.MODEL.DEPTH_NET = CN()
 _C.MODEL.DEPTH_NET.NAME = "DepthResNet"
 _C.MODEL.DEPTH_NET.ENCODER_NAME = "18"
 _C.MODEL.DEPTH_NET.UPSAMPLE_DEPTH = False
+_C.MODEL.DEPTH_NET.VERSION = "1A"          # PackNet01 only (packnet_1a.yaml)
 _C.MODEL.POSE_NET = CN()
 _C.MODEL.POSE_NET.NAME = "PoseNet"
 _C.MODEL.POSE_NET.NUM_CONTEXTS = 2

@@ -67,7 +67,7 @@ class HipBatchNorm2d(nn.Module):
 
 
 class HipGroupNorm(nn.Module):
-    """nn.GroupNorm stand-in fused with the following ReLU (PoseNet.py:L13-20)."""
+    """nn.GroupNorm stand-in fused with the following activation: ReLU (PoseNet.py:L13-20), "elu" (layers01.py:L33-40) or none."""
 
     def __init__(self, num_groups, num_channels, eps=1e-5):
         super().__init__()

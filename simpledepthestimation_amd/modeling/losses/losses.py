@@ -17,3 +17,9 @@ class silog_loss(nn.Module):
 
     def forward(self, depth_est, depth_gt):
         return HP.silog_loss(depth_est, depth_gt, self.variance_focus)
+
+
+def variance_loss(depth):
+    """losses.py:L16-18: 1 / mean((depth / mean(depth) - 1)^2) of one [B,1,h,w] fp32 depth map.  Two scalar reductions over a
+    single-channel map: a handful of device-side torch reductions per scale (PackNet config only, weight 1e-4), no custom kernel."""
+    return 1 / ((depth / depth.mean() - 1.0) ** 2).mean()

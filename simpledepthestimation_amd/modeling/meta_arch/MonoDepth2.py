@@ -10,7 +10,7 @@ from ...hip import nn as HN
 from ...hip import photometric as HP
 from ...utils.memory import to_cuda
 from ..depth_net import build_depth_net
-from ..losses.losses import silog_loss
+from ..losses.losses import silog_loss, variance_loss
 from ..losses.smoothness_loss import smoothness_loss
 from ..losses.ssim_loss import SSIM
 from ..pose_net import build_pose_net
@@ -34,8 +34,6 @@ class MonoDepth2Model(nn.Module):
         self.supervise_loss = silog_loss(cfg.LOSS.VARIANCE_FOCUS)
         if self.clip_loss > 0.0:
             raise NotImplementedError("LOSS.CLIP > 0 (mean + k*std clipping, MonoDepth2.py:L147-149) is 0.0 in every reference config")
-        if self.var_loss_w > 0.0:
-            raise NotImplementedError("LOSS.VAR_LOSS_WEIGHT > 0 is only used by the PackNet config (scheduled with PackNet01)")
         self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(1, -1, 1, 1))
         self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(1, -1, 1, 1))
 
@@ -73,6 +71,8 @@ class MonoDepth2Model(nn.Module):
             if self.sup_loss_w > 0.0:
                 # the reference weights this term with smooth_loss_w (MonoDepth2.py:L109, sic)
                 losses["sup_loss"] += self.supervise_loss(depth_pred[i], batch["depth"]) * (scale_w * self.smooth_loss_w / num_scales)
+            if self.var_loss_w > 0.0:
+                losses["var_loss"] += variance_loss(depth_pred[i]) * (scale_w * self.var_loss_w / num_scales)
         output["rec_loss"] = sum(photo_losses) / num_scales
         output.update(losses)
         return output

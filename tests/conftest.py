@@ -38,3 +38,8 @@ def geo():
 @pytest.fixture(scope="session")
 def mod():
     return _Golden(os.path.join(GOLDEN, "models.npz"))
+
+
+@pytest.fixture(scope="session")
+def pack():
+    return _Golden(os.path.join(GOLDEN, "packnet.npz"))

@@ -152,3 +152,25 @@ def test_monodepth2_model(mod, tag, H, W):
         vec = out["pose_vec"].detach()
         close(G.pose_vec2mat(vec[:, 0]), mod.t("mono18.pose0"), 1e-5, 1e-7)
         close(G.pose_vec2mat(vec[:, 1]), mod.t("mono18.pose1"), 1e-5, 1e-7)
+
+
+@pytest.mark.parametrize("version", ["A", "B"])
+def test_packnet_model(pack, version):
+    """MonoDepth2Model + PackNet01 (packnet_1a.yaml with VAR_LOSS_WEIGHT 1e-4; 1B = the channel-addition variant) vs the reference."""
+    tag = "packnet1" + version
+    sd = _leaf(OM.init_packnet_state_dict(version, seed=5))
+    batch = mono_batch(1, 64, 192, 21)
+    out = OM.monodepth2_forward(sd, batch, tag, var_w=1e-4)
+    close(out["rec_loss"], pack[f"{tag}.rec_loss"], 2e-5)
+    close(out["smooth_loss"], pack[f"{tag}.smooth_loss"], 2e-4)
+    close(out["var_loss"], pack[f"{tag}.var_loss"], 2e-4)
+    names = [k[len(tag) + 7:] for k in pack.keys() if k.startswith(f"{tag}.gnorm.")]
+    gn = _grad_norms(sd, out["rec_loss"] + out["smooth_loss"] + out["var_loss"], names)
+    for n in names:
+        close(gn[n], pack[f"{tag}.gnorm.{n}"], 5e-3, 1e-8)
+    with torch.no_grad():
+        x = OM.normalise(sd, batch["img"])
+        depths = N.packnet01({k: v.detach() for k, v in sd.items()}, x, version)
+        for i, d in enumerate(depths):
+            close(d, pack.t(f"{tag}.depth{i}"), 1e-4, 1e-6)
+        close(N.packnet01({k: v.detach() for k, v in sd.items()}, x, version, flip=True)[0], pack.t(f"{tag}.flip_depth0"), 1e-4, 1e-6)
