@@ -205,16 +205,8 @@ struct PhotoArgs {
     float sx, sy, ssim_w, C1, C2;
 };
 
-// SSIM distance of channel data held in LDS planes (x: candidate, y: target), at LDS position p (row stride FT_W)
-__device__ __forceinline__ float ssim_dist(const float* __restrict__ xs, const float* __restrict__ ys, int p, float C1, float C2) {
-    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const float x = xs[p + dy * FT_W + dx], y = ys[p + dy * FT_W + dx];
-            sx += x; sy += y; sxx += x * x; syy += y * y; sxy += x * y;
-        }
+// clamp((1 - SSIM)/2, 0, 1) from the nine-tap sums (ssim_loss.py:L34-53: mu = avgpool3x3, sigma = E[x^2] - mu^2)
+__device__ __forceinline__ float ssim_from_moments(float sx, float sy, float sxx, float syy, float sxy, float C1, float C2) {
     const float inv9 = 1.0f / 9.0f;
     const float mx = sx * inv9, my = sy * inv9;
     const float mxy = mx * my, mxx = mx * mx, myy = my * my;
@@ -243,10 +235,15 @@ __global__ void __launch_bounds__(FT_N) photo_fwd_kernel(PhotoArgs a) {
     const float d = usable ? a.depth[b * hw + pix] : 1.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) sA[c * FT_N + lp] = usable ? a.A[((long)b * 3 + c) * hw + pix] : 0.f;
+    // the camera matrices are per (sample, context): one thread each builds them, everybody reads them back (LDS broadcast)
+    __shared__ Cam scam[NCTX];
+#pragma unroll
+    for (int j = 0; j < NCTX; ++j)
+        if (lp == j) make_cam(a.K + 9 * b, a.pose[j] + 16 * b, a.sx, a.sy, scam[j]);
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < NCTX; ++j) {
-        Cam cam;
-        make_cam(a.K + 9 * b, a.pose[j] + 16 * b, a.sx, a.sy, cam);
+        const Cam cam = scam[j];
         Proj pr;
         project(cam, rx, ry, d, w, h, pr);
         Taps t;
@@ -265,24 +262,53 @@ __global__ void __launch_bounds__(FT_N) photo_fwd_kernel(PhotoArgs a) {
     const bool interior = tx >= 1 && tx < FT_W - 1 && ty >= 1 && ty < FT_H - 1 && inimg;
     if (interior) {
         const int nmaps = a.automask ? 2 * NCTX : NCTX;
+        // channel-outer / map-inner: the 3x3 moments of the target frame (sum y, sum y^2) and its nine values are shared by all
+        // maps of a channel; every individual sum keeps the operand order of ssim_dist(), so the results are unchanged bit for bit
+        float l1[2 * NCTX], ss[2 * NCTX];
+#pragma unroll
+        for (int m = 0; m < 2 * NCTX; ++m) { l1[m] = 0.f; ss[m] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* ys = sA + c * FT_N;
+            float y[9], sy = 0.f, syy = 0.f;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int k = (dy + 1) * 3 + dx + 1;
+                    y[k] = ys[lp + dy * FT_W + dx];
+                    sy += y[k]; syy += y[k] * y[k];
+                }
+#pragma unroll
+            for (int m = 0; m < 2 * NCTX; ++m) {
+                const int j = m >> 1;
+                const bool ident = m & 1;
+                if (ident && !a.automask) continue;
+                const float* xs = (ident ? sC : sS) + (j * 3 + c) * FT_N;
+                l1[m] += fabsf(xs[lp] - y[4]);
+                if (a.ssim_w > 0.f) {
+                    float sx = 0.f, sxx = 0.f, sxy = 0.f;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const float x = xs[lp + dy * FT_W + dx], yk = y[(dy + 1) * 3 + dx + 1];
+                            sx += x; sxx += x * x; sxy += x * yk;
+                        }
+                    ss[m] += ssim_from_moments(sx, sy, sxx, syy, sxy, a.C1, a.C2);
+                }
+            }
+        }
         float best = 0.f, acc = 0.f;
         int bi = 0;
 #pragma unroll
         for (int m = 0; m < 2 * NCTX; ++m) {
-            const int j = m >> 1;
             const bool ident = m & 1;
             if (ident && !a.automask) continue;
-            const float* X = (ident ? sC : sS) + j * 3 * FT_N;
-            float l1 = 0.f, ss = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                l1 += fabsf(X[c * FT_N + lp] - sA[c * FT_N + lp]);
-                if (a.ssim_w > 0.f) ss += ssim_dist(X + c * FT_N, sA + c * FT_N, lp, a.C1, a.C2);
-            }
-            l1 = l1 / 3.0f;
-            float pm = l1;
-            if (a.ssim_w > 0.f) pm = (ss / 3.0f) * a.ssim_w + l1 * (1.0f - a.ssim_w);
-            const int mi = a.automask ? m : j;
+            const float l = l1[m] / 3.0f;
+            float pm = l;
+            if (a.ssim_w > 0.f) pm = (ss[m] / 3.0f) * a.ssim_w + l * (1.0f - a.ssim_w);
+            const int mi = a.automask ? m : (m >> 1);
             if (a.maps) a.maps[(((long)b * nmaps + mi) * h + gy) * w + gx] = pm;
             acc += pm;
             if (mi == 0 || pm < best) { best = pm; bi = mi; }
