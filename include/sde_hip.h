@@ -132,15 +132,18 @@ typedef struct sde_conv_desc {
 int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int KH, int KW, int Cin_pad, int Cout_pad, int for_dgrad,
                     sde_stream_t stream);
 
-/* The same for every layer of a model in ONE launch (the weights change once per optimizer step).  items: DEVICE array of n jobs;
- * `end` = exclusive prefix sum of the jobs' output element counts, total = items[n-1].end. */
+/* Both operands of every layer of a model in ONE launch (the weights change once per optimizer step).  items: DEVICE array of n layers,
+ * built once; a workgroup transposes one (32 output channels x sde-chosen input-channel block x all taps) tile through LDS;
+ * `end` = exclusive prefix sum of sde_pack_item_blocks() over the layers, total_blocks = items[n-1].end. */
 typedef struct sde_pack_item {
-    const float* src; /* master OIHW fp32 */
-    void* dst;        /* packed operand in `dtype` */
-    int32_t Cout, Cin, KH, KW, Cin_pad, Cout_pad, for_dgrad, reserved;
+    const float* src; /* master OIHW fp32 [Cout][Cin][KH][KW] */
+    void* dst_fwd;    /* [Cout_pad][KH][KW][Cin_pad] in `dtype` (or NULL) */
+    void* dst_dgrad;  /* [Cin_pad][KH][KW][Cout_pad], taps flipped (or NULL) */
+    int32_t Cout, Cin, KH, KW, Cin_pad, Cout_pad;
     int64_t end;
 } sde_pack_item;
-int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total, int dtype, sde_stream_t stream);
+int sde_pack_item_blocks(int Cout_pad, int Cin_pad, int KH, int KW);
+int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total_blocks, int dtype, sde_stream_t stream);
 
 /* y[Bn,OH,OW,ldy] = act(conv(virtual input, w_packed) + bias); channels >= Cout of y are written as zeros.
  * Replaces nn.Conv2d (+ReflectionPad2d, +upsample/cat, +nn.ELU) forward -- resnet_encoder.py:L91-97, depth_decoder.py:L21-53,

@@ -988,28 +988,57 @@ __global__ void __launch_bounds__(256) pack_w_dgrad_kernel(const float* __restri
     }
 }
 
-// All layers' operands in ONE launch: items[] (device) describe each pack job; `end` is the exclusive prefix sum of output
-// elements, so a grid-stride index finds its job by binary search.
+// All layers' operands in ONE launch.  items[] (device, built once per model) describe each layer; a workgroup owns a
+// (32 output channels) x (PACK_CI(khw) input channels) x (all taps) tile of one layer: the OIHW rows are read ONCE, coalesced, into
+// LDS and written out twice -- as the forward operand [co][tap][ci] and as the tap-flipped data-gradient operand [ci][tap][co] --
+// in contiguous runs.  (The per-element form of this kernel re-fetched every 128-byte line of the master weights ~khw times with
+// 64 distinct lines per wave instruction and cost 0.41 ms per step on ResNet-50; `end` = exclusive prefix sum of the tiles.)
+constexpr int PACK_CO = 32, PACK_LDS_FLOATS = 12800;
+__host__ __device__ inline int pack_ci(int khw) {        // input channels per tile: multiple of 8, 32*ci*khw floats fit the LDS tile
+    int c = (PACK_LDS_FLOATS / PACK_CO - 1) / khw;
+    c &= ~7;
+    return c < 8 ? 8 : (c > 256 ? 256 : c);
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) pack_batched_kernel(const sde_pack_item* __restrict__ items, int n, long total) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int lo = 0, hi = n - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (items[mid].end > i) hi = mid; else lo = mid + 1;
+__global__ void __launch_bounds__(256) pack_batched_kernel(const sde_pack_item* __restrict__ items, int n) {
+    __shared__ float tile[PACK_LDS_FLOATS];
+    int lo = 0, hi = n - 1;
+    const long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (items[mid].end > b) hi = mid; else lo = mid + 1;
+    }
+    const sde_pack_item it = items[lo];
+    const int local = (int)(b - (lo ? items[lo - 1].end : 0));
+    const int khw = it.KH * it.KW, CI = pack_ci(khw);
+    const int tiles_ci = (it.Cin_pad + CI - 1) / CI;
+    const int co0 = (local / tiles_ci) * PACK_CO, ci0 = (local % tiles_ci) * CI;
+    const int n_ci_real = max(0, min(CI, it.Cin - ci0));          // channels that exist in the master weights
+    const int n_ci = min(CI, it.Cin_pad - ci0), n_co = min(PACK_CO, it.Cout_pad - co0);
+    const int seg = n_ci_real * khw, rs = CI * khw + 1;           // row stride odd: the transposed reads below are conflict-free
+    if (seg > 0)
+        for (int idx = threadIdx.x; idx < PACK_CO * seg; idx += 256) {
+            const int co_l = idx / seg, e = idx - co_l * seg;
+            const int co = co0 + co_l;
+            tile[co_l * rs + e] = co < it.Cout ? it.src[((size_t)co * it.Cin + ci0) * khw + e] : 0.f;
         }
-        const sde_pack_item it = items[lo];
-        const long j = i - (lo ? items[lo - 1].end : 0);
-        const int khw = it.KH * it.KW;
-        float v = 0.f;
-        if (!it.for_dgrad) {          // [Cout_pad][KH][KW][Cin_pad]
-            const int ci = (int)(j % it.Cin_pad), tap = (int)((j / it.Cin_pad) % khw), co = (int)(j / ((long)it.Cin_pad * khw));
-            if (ci < it.Cin && co < it.Cout) v = it.src[((size_t)co * it.Cin + ci) * khw + tap];
-        } else {                      // [Cin_pad][KH][KW][Cout_pad], taps flipped
-            const int co = (int)(j % it.Cout_pad), tapf = (int)((j / it.Cout_pad) % khw), ci = (int)(j / ((long)it.Cout_pad * khw));
-            if (ci < it.Cin && co < it.Cout) v = it.src[((size_t)co * it.Cin + ci) * khw + (khw - 1 - tapf)];
+    __syncthreads();
+    if (it.dst_fwd) {             // [Cout_pad][khw][Cin_pad]
+        T* dst = (T*)it.dst_fwd;
+        for (int idx = threadIdx.x; idx < n_co * khw * n_ci; idx += 256) {
+            const int ci_l = idx % n_ci, t2 = idx / n_ci, tap = t2 % khw, co_l = t2 / khw;
+            const float v = (ci_l < n_ci_real && co0 + co_l < it.Cout) ? tile[co_l * rs + ci_l * khw + tap] : 0.f;
+            dst[((size_t)(co0 + co_l) * khw + tap) * it.Cin_pad + ci0 + ci_l] = from_f32<T>(v);
         }
-        ((T*)it.dst)[j] = from_f32<T>(v);
+    }
+    if (it.dst_dgrad) {           // [Cin_pad][khw][Cout_pad], taps flipped
+        T* dst = (T*)it.dst_dgrad;
+        for (int idx = threadIdx.x; idx < n_ci * khw * n_co; idx += 256) {
+            const int co_l = idx % n_co, t2 = idx / n_co, tapf = t2 % khw, ci_l = t2 / khw;
+            const float v = (ci_l < n_ci_real && co0 + co_l < it.Cout) ? tile[co_l * rs + ci_l * khw + (khw - 1 - tapf)] : 0.f;
+            dst[((size_t)(ci0 + ci_l) * khw + tapf) * it.Cout_pad + co0 + co_l] = from_f32<T>(v);
+        }
     }
 }
 
@@ -1346,13 +1375,16 @@ int sde_conv_set_halo_min_blocks(int min_blocks) {
     return old;
 }
 
-int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total, int dtype, sde_stream_t stream) {
-    SDE_CHECK_ARG(items_dev && n > 0 && total > 0, "sde_pack_weights_batched: bad argument");
+int sde_pack_item_blocks(int Cout_pad, int Cin_pad, int KH, int KW) {
+    if (Cout_pad <= 0 || Cin_pad <= 0 || KH <= 0 || KW <= 0 || (long)PACK_CO * 8 * KH * KW + PACK_CO > PACK_LDS_FLOATS) return -1;
+    return sde_cdiv(Cout_pad, PACK_CO) * sde_cdiv(Cin_pad, pack_ci(KH * KW));
+}
+
+int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total_blocks, int dtype, sde_stream_t stream) {
+    SDE_CHECK_ARG(items_dev && n > 0 && total_blocks > 0 && total_blocks < 0x7fffffffL, "sde_pack_weights_batched: bad argument");
     SDE_CHECK_ARG(dtype == SDE_F32 || dtype == SDE_BF16, "sde_pack_weights_batched: bad dtype");
-    long nb = (total + 255) / 256;
-    if (nb > 16384) nb = 16384;
-    if (dtype == SDE_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, items_dev, n, total);
-    else hipLaunchKernelGGL(pack_batched_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, items_dev, n, total);
+    if (dtype == SDE_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n);
+    else hipLaunchKernelGGL(pack_batched_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n);
     SDE_CHECK_LAUNCH("sde_pack_weights_batched");
     return SDE_OK;
 }

@@ -26,6 +26,7 @@ _P, _I, _F, _LG = c_void_p, c_int, c_float, c_long
 L.register_protos({
     "sde_pack_weight": ([_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
     "sde_pack_weights_batched": ([_P, _I, _LG, _I, _P], c_int),
+    "sde_pack_item_blocks": ([_I, _I, _I, _I], c_int),
     "sde_conv_fwd": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P], c_int),
     "sde_conv_fwd_tiles_m": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_fwd_variant": ([POINTER(ConvDesc), _I], c_int),
@@ -317,8 +318,8 @@ FOLD_ROWS = 16          # SDE_WGRAD_FOLD_ROWS
 
 
 class PackItem(Structure):
-    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("Cout", c_int32), ("Cin", c_int32), ("KH", c_int32), ("KW", c_int32), ("Cin_pad", c_int32),
-                ("Cout_pad", c_int32), ("for_dgrad", c_int32), ("reserved", c_int32), ("end", ctypes.c_int64)]
+    _fields_ = [("src", c_void_p), ("dst_fwd", c_void_p), ("dst_dgrad", c_void_p), ("Cout", c_int32), ("Cin", c_int32), ("KH", c_int32), ("KW", c_int32),
+                ("Cin_pad", c_int32), ("Cout_pad", c_int32), ("end", ctypes.c_int64)]
 
 
 class WeightPacker:
@@ -344,9 +345,11 @@ class WeightPacker:
             wp = torch.empty(ldy, KH, KW, cin_pad, device=w.device, dtype=dt)
             wd = torch.empty(cin_pad, KH, KW, ldy, device=w.device, dtype=dt)
             m._packed = (wp, wd)
-            for dst, for_dgrad in ((wp, 0), (wd, 1)):
-                end += dst.numel()
-                items.append((w.data_ptr(), dst.data_ptr(), Cout, Cin, KH, KW, cin_pad, ldy, for_dgrad, 0, end))
+            nb = L.lib().sde_pack_item_blocks(ldy, cin_pad, KH, KW)
+            if nb <= 0:
+                raise L.SdeHipError(f"WeightPacker: unsupported kernel size {KH}x{KW}")
+            end += nb
+            items.append((w.data_ptr(), wp.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, cin_pad, ldy, end))
             self._keep.append((w, wp, wd))
         arr = (PackItem * len(items))(*[PackItem(*it) for it in items])
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()

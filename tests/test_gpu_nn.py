@@ -311,6 +311,26 @@ def test_conv3d_pack(NN, dtype, B, D, H, W):
     check(bd.grad.cpu(), br.grad, dtype, "conv3d dbias", 2e-5, 2e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_packer_equals_per_layer_pack(NN, dtype):
+    """sde_pack_weights_batched (LDS-tiled, every layer in one launch) == sde_pack_weight per layer and operand, bit for bit."""
+    from simpledepthestimation_amd.layers.hip_modules import HipConv2d
+    V = 4 if dtype == torch.float32 else 8
+    shapes = [(3, 64, 7), (64, 64, 3), (193, 128, 3), (256, 64, 5), (64, 256, 1), (16, 1, 3), (520, 40, 3), (2048, 24, 1)]
+    torch.manual_seed(5)
+    net = torch.nn.ModuleList([HipConv2d(ci, co, k, padding=k // 2) for ci, co, k in shapes]).to(dev)
+    for m, (ci, co, k) in zip(net, shapes):
+        x = torch.zeros(1, 8, 8, (ci + V - 1) // V * V, device=dev, dtype=dtype)
+        m(x)                                   # records the padded operand shapes
+    packer = NN.WeightPacker(net)
+    packer.run()
+    for m, (ci, co, k) in zip(net, shapes):
+        dt, cin_pad, ldy = m._pack_shapes
+        wp, wd = m._packed
+        assert torch.equal(wp, NN.pack_weight(m.weight, dt, cin_pad, ldy, for_dgrad=False)), f"forward operand {ci}->{co} k{k}"
+        assert torch.equal(wd, NN.pack_weight(m.weight, dt, cin_pad, ldy, for_dgrad=True)), f"dgrad operand {ci}->{co} k{k}"
+
+
 def test_prep_input(NN):
     g = torch.Generator().manual_seed(3)
     img = torch.rand(2, 3, 10, 14, generator=g)
