@@ -1062,8 +1062,12 @@ int launch_igemm(const IGemmP& p, hipStream_t s) {
 
 // Tile choice (one place): returns BM*1000 + BN.  Small-N layers get narrow N tiles (the GEMM is then A-bandwidth bound);
 // layers whose 128x128 grid would not fill the 256 CUs fall back to 64x64 tiles.
-int pick_tile(long M, int N) {
+int pick_tile(long M, int N, int Ktot) {
     const long tiles128 = (long)sde_cdiv(M, 128) * sde_cdiv(N, 128);
+    // experiment knob: K <= SDE_SHORTK (elements) runs one or two pipeline stages, so the tile is all prologue / epilogue latency and
+    // 64x64 tiles (32 KB of LDS, 4+ workgroups per CU instead of 2) may hide it better
+    static const int shortk = [] { const char* e = getenv("SDE_SHORTK"); return e ? atoi(e) : 0; }();
+    if (Ktot <= shortk && N > 32) return 64064;
     if (N > 64) return (tiles128 < 192) ? 64064 : 128128;
     if (N > 32) return (sde_cdiv(M, 128) < 192) ? 64064 : 128064;
     if (N > 16) return 128032;
@@ -1149,7 +1153,7 @@ int dispatch_halo(const IGemmP& p, hipStream_t s) {
 
 template <typename T>
 int dispatch_igemm(const IGemmP& p, hipStream_t s) {
-    switch (pick_tile(p.g.M, p.ldy)) {
+    switch (pick_tile(p.g.M, p.ldy, p.g.Ktot)) {
         case 128128: return dispatch_src<T, 128, 128, 2, 2>(p, s);
         case 128064: return dispatch_src<T, 128, 64, 2, 2>(p, s);
         case 128032: return dispatch_src<T, 128, 32, 4, 1>(p, s);
@@ -1248,7 +1252,7 @@ static int gather_of(const sde_conv_desc* d, Gather& g) { return fill_gather(d, 
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
     Gather g;
     if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return 3128000 + halo_bn(g, ldy);      // 3128<BN>: LDS-halo 3x3 kernel
-    return pick_tile((long)d->Bn * d->OH * d->OW, ldy);
+    return pick_tile((long)d->Bn * d->OH * d->OW, ldy, d->KH * d->KW * (d->C0 + d->C1));
 }
 
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
@@ -1256,7 +1260,7 @@ int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
     Gather g;
     if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return halo_tiles_m(g);
     const long M = (long)d->Bn * d->OH * d->OW;
-    return sde_cdiv(M, pick_tile(M, ldy) / 1000);
+    return sde_cdiv(M, pick_tile(M, ldy, d->KH * d->KW * (d->C0 + d->C1)) / 1000);
 }
 
 int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
