@@ -279,16 +279,18 @@ def test_packnet_vs_reference_golden(pack, version):
     state = dict(sd); state.update(leaves)
     o = OM.monodepth2_forward(state, batch, tag, var_w=1e-4)
     (o["rec_loss"] + o["smooth_loss"] + o["var_loss"]).backward()
-    worst = 0.0
+    worst, bad = 0.0, []
     norms = sorted(float(v.grad.norm()) for v in leaves.values() if v.grad is not None)
-    floor = 1e-3 * norms[len(norms) // 2]       # gradients that are zero in exact arithmetic (a conv bias in front of a GroupNorm with one
+    floor = 1e-2 * norms[len(norms) // 2]       # gradients that are zero in exact arithmetic (a conv bias in front of a GroupNorm with one
     for n, p in named.items():                  # channel per group) are rounding noise on both sides: measure errors against this floor
         ref = leaves[n].grad
         if ref is None or ref.numel() == 1:
             continue        # 1-element gradients (the InvDepth biases) are sums with heavy cancellation: fp32 order noise on both sides
         e = (p.grad.detach().double().cpu() - ref.double()).norm().item() / (ref.double().norm().item() + floor)
         worst = max(worst, e)
-        assert e < 2e-2, f"{n}: gradient relative error {e:.3e}"
+        if e >= 2e-2:
+            bad.append(f"{n}: {e:.3e}")
+    assert not bad, "gradient relative errors: " + "; ".join(bad)
     assert worst > 0
     model.eval()
     with torch.no_grad():
