@@ -588,6 +588,23 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
         for (long i = threadIdx.x; i < total; i += 256) { const float v = (float)base[i]; a1 += v; a2 += v * v; }
         (void)c;
         fixed_order_channel_sum(a1, a2, C, sh);
+    } else if (C % 256 == 0 && C <= 2048) {
+        // channel c is walked by exactly one thread (c % 256), in slot c / 256: no cross-thread combination at all
+        float b1[8], b2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { b1[j] = 0.f; b2[j] = 0.f; }
+        const int slots = C / 256;
+        int slot = 0;
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const float v = (float)base[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j == slot) { b1[j] += v; b2[j] += v * v; }
+            if (++slot == slots) slot = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < slots) { sh[threadIdx.x + 256 * j] = b1[j]; sh[C + threadIdx.x + 256 * j] = b2[j]; }
     } else {
         for (long i = threadIdx.x; i < total; i += 256) {
             const int c = (int)(i % C);
@@ -655,6 +672,26 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
             a1 += d; a2 += d * xh;
         }
         fixed_order_channel_sum(a1, a2, C, sh);
+    } else if (C % 256 == 0 && C <= 2048) {
+        float b1[8], b2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { b1[j] = 0.f; b2[j] = 0.f; }
+        const int slots = C / 256;
+        int slot = 0;
+        for (long i = threadIdx.x; i < total; i += 256) {
+            const int c = threadIdx.x + 256 * slot;
+            const float* st = gnp + ((size_t)b * G + c / cpg) * 2;
+            float d = (float)dout[base + i];
+            if (relu) d = gn_act_grad(d, (float)out[base + i], relu);
+            const float xh = ((float)x[base + i] - st[0]) * st[1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j == slot) { b1[j] += d; b2[j] += d * xh; }
+            if (++slot == slots) slot = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < slots) { sh[threadIdx.x + 256 * j] = b1[j]; sh[C + threadIdx.x + 256 * j] = b2[j]; }
     } else {
         for (long i = threadIdx.x; i < total; i += 256) {
             const int c = (int)(i % C);
