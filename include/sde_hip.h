@@ -219,7 +219,8 @@ int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, 
                        sde_stream_t stream);
 
 /* nn.GroupNorm(G) + activation: relu = 0 none, 1 nn.ReLU (PoseNet.py:L13-20), 2 nn.ELU (layers01.py:L33-40).
- * part: [B][16][C][2] workspace, gnp: [B][G][2] (mean, rstd) saved for backward, coef: [B][G][2] workspace. */
+ * part: [B][SDE_GN_CHUNKS][C][2] workspace, gnp: [B][G][2] (mean, rstd) saved for backward, coef: [B][G][2] workspace. */
+#define SDE_GN_CHUNKS 64
 int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype, float* part, float* gnp,
                     void* out, sde_stream_t stream);
 int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,

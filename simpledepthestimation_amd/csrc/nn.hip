@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(256) depth_head_bwd_kernel(const T* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 // GroupNorm(G) + ReLU, NHWC.  Stage 1: per (sample, chunk-of-pixels) per-channel (sum, sum^2) partials.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int GN_CHUNKS = 16;
+constexpr int GN_CHUNKS = SDE_GN_CHUNKS;    // pixel chunks per sample (workgroups of the statistics kernels: B x GN_CHUNKS)
 
 // activation fused behind the normalisation: 0 none, 1 ReLU (PoseNet.py:L13-20), 2 ELU (layers01.py:L33-40); the derivative is taken
 // from the stored output, as the reference's in-place activations do
@@ -571,6 +571,26 @@ __device__ __forceinline__ void fixed_order_channel_sum(float a1, float a2, int 
     }
 }
 
+// 16-byte variant: thread t walks the channel group t % cch (cch = C / V divides 256); the 256 / cch threads of a group are combined
+// in thread order through LDS.  a1 / a2: the thread's V partial sums each.  sh = [2][C].
+template <int V>
+__device__ __forceinline__ void fixed_order_group_sum(const float* a1, const float* a2, int cch, float* sh, int C) {
+    __shared__ float red[256 * 2 * V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[(threadIdx.x * 2) * V + e] = a1[e]; red[(threadIdx.x * 2 + 1) * V + e] = a2[e]; }
+    __syncthreads();
+    if ((int)threadIdx.x < cch) {
+        float t1[V], t2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+        for (int r = threadIdx.x; r < 256; r += cch)
+#pragma unroll
+            for (int e = 0; e < V; ++e) { t1[e] += red[(r * 2) * V + e]; t2[e] += red[(r * 2 + 1) * V + e]; }
+#pragma unroll
+        for (int e = 0; e < V; ++e) { sh[threadIdx.x * V + e] = t1[e]; sh[C + threadIdx.x * V + e] = t2[e]; }
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ part /*[B][GN_CHUNKS][C][2]*/) {
     extern __shared__ float sh[];   // [2][C]
@@ -582,6 +602,21 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
     const long total = (long)(p1 - p0) * C;
     const T* base = x + ((long)b * HW + p0) * C;
     float a1 = 0.f, a2 = 0.f;
+    constexpr int V = VecOf<T>::V;
+    if (C % V == 0 && 256 % (C / V) == 0) {          // 16 bytes per lane, fixed channel group per thread
+        const int cch = C / V;
+        float v1[V], v2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { v1[e] = 0.f; v2[e] = 0.f; }
+        const long groups = (long)(p1 - p0) * cch;
+        for (long i = threadIdx.x; i < groups; i += 256) {
+            float v[V];
+            load_vec<T>(base + i * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) { v1[e] += v[e]; v2[e] += v[e] * v[e]; }
+        }
+        fixed_order_group_sum<V>(v1, v2, cch, sh, C);
+    } else
     // thread walks elements with a fixed channel when 256 % C == 0 (C <= 256), else falls back to shared atomics per element
     if (256 % C == 0) {
         const int c = threadIdx.x % C;
@@ -638,13 +673,19 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict
 template <typename T>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ gnp, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int B, int HW, int C, int G, int relu, T* __restrict__ out) {
-    const long total = (long)B * HW * C;
-    const int cpg = C / G;
+    constexpr int V = VecOf<T>::V;                 // 16 bytes per lane
+    const int cch = C / V, cpg = C / G;
+    const long total = (long)B * HW * cch;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
-        const float* st = gnp + ((size_t)b * G + c / cpg) * 2;
-        float v = ((float)x[i] - st[0]) * st[1] * gamma[c] + beta[c];
-        out[i] = (T)gn_act(v, relu);
+        const int c0 = (int)(i % cch) * V, b = (int)(i / ((long)HW * cch));
+        float v[V];
+        load_vec<T>(x + i * V, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float* st = gnp + ((size_t)b * G + (c0 + e) / cpg) * 2;
+            v[e] = gn_act((v[e] - st[0]) * st[1] * gamma[c0 + e] + beta[c0 + e], relu);
+        }
+        store_vec<T>(out + i * V, v);
     }
 }
 
@@ -661,6 +702,30 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
     const int p0 = ch * per, p1 = min(HW, p0 + per);
     const long total = (long)(p1 - p0) * C;
     const long base = ((long)b * HW + p0) * C;
+    constexpr int V = VecOf<T>::V;
+    if (C % V == 0 && 256 % (C / V) == 0) {
+        const int cch = C / V, c0 = (threadIdx.x % cch) * V;
+        float m_[V], r_[V], v1[V], v2[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float* st = gnp + ((size_t)b * G + (c0 + e) / cpg) * 2;
+            m_[e] = st[0]; r_[e] = st[1]; v1[e] = 0.f; v2[e] = 0.f;
+        }
+        const long groups = (long)(p1 - p0) * cch;
+        for (long i = threadIdx.x; i < groups; i += 256) {
+            float d[V], o[V], xv[V];
+            load_vec<T>(dout + base + i * V, d);
+            if (relu) load_vec<T>(out + base + i * V, o);
+            load_vec<T>(x + base + i * V, xv);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float de = d[e];
+                if (relu) de = gn_act_grad(de, o[e], relu);
+                v1[e] += de; v2[e] += de * ((xv[e] - m_[e]) * r_[e]);
+            }
+        }
+        fixed_order_group_sum<V>(v1, v2, cch, sh, C);
+    } else
     if (256 % C == 0) {
         const int c = threadIdx.x % C;
         const float* st = gnp + ((size_t)b * G + c / cpg) * 2;
@@ -740,15 +805,24 @@ template <typename T>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
                                                            const float* __restrict__ gnp, const float* __restrict__ coef, const float* __restrict__ gamma,
                                                            int B, int HW, int C, int G, int relu, T* __restrict__ dx) {
-    const long total = (long)B * HW * C;
-    const int cpg = C / G;
+    constexpr int V = VecOf<T>::V;
+    const int cch = C / V, cpg = C / G;
+    const long total = (long)B * HW * cch;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
-        const size_t gi = ((size_t)b * G + c / cpg) * 2;
-        float d = (float)dout[i];
-        if (relu) d = gn_act_grad(d, (float)out[i], relu);
-        const float xh = ((float)x[i] - gnp[gi]) * gnp[gi + 1];
-        dx[i] = (T)(gnp[gi + 1] * (gamma[c] * d - coef[gi] - xh * coef[gi + 1]));
+        const int c0 = (int)(i % cch) * V, b = (int)(i / ((long)HW * cch));
+        float d[V], o[V], xv[V];
+        load_vec<T>(dout + i * V, d);
+        if (relu) load_vec<T>(out + i * V, o);
+        load_vec<T>(x + i * V, xv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const size_t gi = ((size_t)b * G + (c0 + e) / cpg) * 2;
+            float de = d[e];
+            if (relu) de = gn_act_grad(de, o[e], relu);
+            const float xh = (xv[e] - gnp[gi]) * gnp[gi + 1];
+            d[e] = gnp[gi + 1] * (gamma[c0 + e] * de - coef[gi] - xh * coef[gi + 1]);
+        }
+        store_vec<T>(dx + i * V, d);
     }
 }
 
@@ -967,6 +1041,7 @@ int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, 
 int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype, float* part, float* gnp,
                     void* out, sde_stream_t stream) {
     SDE_CHECK_ARG(x && gamma && beta && part && gnp && out && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "sde_gn_relu_fwd: bad argument");
+    SDE_CHECK_ARG(C % (dtype == SDE_BF16 ? 8 : 4) == 0, "sde_gn_relu_fwd: C=%d must be a multiple of the 16-byte group", C);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)x, HW, C, part),
@@ -974,7 +1049,7 @@ int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B,
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/stats");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(sde_cdiv(B * G, 64)), dim3(64), 0, s, part, B, C, G, HW, eps, gnp);
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/finalize");
-    const int nb = grid_for((long)B * HW * C);
+    const int nb = grid_for((long)B * HW * (C / (dtype == SDE_BF16 ? 8 : 4)));
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, gnp, gamma, beta, B, HW, C, G, relu, (float*)out),
                hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, gnp, gamma, beta, B, HW, C, G, relu, (bf16_t*)out));
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/apply");
@@ -984,6 +1059,7 @@ int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B,
 int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,
                     float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream) {
     SDE_CHECK_ARG(dout && out && x && gnp && gamma && part && coef && dgamma && dbeta && dx && C % G == 0, "sde_gn_relu_bwd: bad argument");
+    SDE_CHECK_ARG(C % (dtype == SDE_BF16 ? 8 : 4) == 0, "sde_gn_relu_bwd: C=%d must be a multiple of the 16-byte group", C);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     DISPATCH_T(dtype,
@@ -993,7 +1069,7 @@ int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const floa
     const int n = B * G > C ? B * G : C;
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(sde_cdiv(n, 64)), dim3(64), 0, s, part, gamma, B, C, G, HW, coef, dgamma, dbeta, accumulate_params);
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/finalize");
-    const int nb = grid_for((long)B * HW * C);
+    const int nb = grid_for((long)B * HW * (C / (dtype == SDE_BF16 ? 8 : 4)));
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, gnp, coef, gamma, B, HW, C, G, relu, (float*)dx),
                hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, coef, gamma, B, HW, C, G, relu, (bf16_t*)dx));

@@ -508,7 +508,7 @@ class _GroupNormReLU(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, groups, eps, relu):
         B, H, W, C = x.shape
         dev = x.device
-        part = torch.empty(B, 16, C, 2, device=dev)
+        part = torch.empty(B, GN_CHUNKS, C, 2, device=dev)
         gnp = torch.empty(B, groups, 2, device=dev)
         out = torch.empty_like(x)
         L.check(L.lib().sde_gn_relu_fwd(L.ptr(x.contiguous()), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), B, H * W, C, groups, eps, int(relu), dtype_code(x.dtype),
@@ -524,7 +524,7 @@ class _GroupNormReLU(torch.autograd.Function):
         groups, relu = ctx.cfg
         B, H, W, C = x.shape
         dev = x.device
-        part = torch.empty(B, 16, C, 2, device=dev)
+        part = torch.empty(B, GN_CHUNKS, C, 2, device=dev)
         coef = torch.empty(B, groups, 2, device=dev)
         gs, bs = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
         direct = gs is not None and bs is not None
@@ -539,6 +539,7 @@ class _GroupNormReLU(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None
 
 
+GN_CHUNKS = 64          # SDE_GN_CHUNKS
 GN_ACT = {False: 0, True: 1, "none": 0, "relu": 1, "elu": 2}
 
 
