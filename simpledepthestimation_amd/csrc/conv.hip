@@ -1063,13 +1063,14 @@ int launch_igemm(const IGemmP& p, hipStream_t s) {
 // Tile choice (one place): returns BM*1000 + BN.  Small-N layers get narrow N tiles (the GEMM is then A-bandwidth bound);
 // layers whose 128x128 grid would not fill the 256 CUs fall back to 64x64 tiles.
 int pick_tile(long M, int N, int Ktot) {
-    const long tiles128 = (long)sde_cdiv(M, 128) * sde_cdiv(N, 128);
-    // experiment knob: K <= SDE_SHORTK (elements) runs one or two pipeline stages, so the tile is all prologue / epilogue latency and
-    // 64x64 tiles (32 KB of LDS, 4+ workgroups per CU instead of 2) may hide it better
-    static const int shortk = [] { const char* e = getenv("SDE_SHORTK"); return e ? atoi(e) : 0; }();
-    if (Ktot <= shortk && N > 32) return 64064;
-    if (N > 64) return (tiles128 < 192) ? 64064 : 128128;
-    if (N > 32) return (sde_cdiv(M, 128) < 192) ? 64064 : 128064;
+    // Measured end to end (Supervised R50, bs 12): 64x64 tiles for every N > 64 layer 10.10 ms/step, 128x64 10.28, 128x128 10.47.
+    // The loop is latency-bound, not MFMA-bound: the 64x64 kernel needs 111 VGPRs and 32 KB of LDS (4 workgroups per CU), the 128x128
+    // one 222 VGPRs and 70 KB (2 per CU), and occupancy wins over operand reuse.  SDE_TILE_BIG / SDE_TILE_MID re-open the choice.
+    static const int big = [] { const char* e = getenv("SDE_TILE_BIG"); return e ? atoi(e) : 64064; }();       // N > 64:  64064 | 128064 | 128128
+    static const int mid = [] { const char* e = getenv("SDE_TILE_MID"); return e ? atoi(e) : 128064; }();      // 32 < N <= 64: 128064 | 64064
+    (void)Ktot;
+    if (N > 64) return big;
+    if (N > 32) return (sde_cdiv(M, 128) < 192) ? 64064 : mid;
     if (N > 16) return 128032;
     return 128016;
 }
@@ -1190,7 +1191,11 @@ int dispatch_wsrc(const WGradP& p, int splits, hipStream_t s) {
     }
 }
 
-int wgrad_bmg(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : (Cout > 16 ? 32 : 16)); }
+int wgrad_bmg(int Cout) {
+    static const int cap = [] { const char* e = getenv("SDE_WGRAD_BMG"); const int v = e ? atoi(e) : 0; return v == 64 ? 64 : 128; }();   // experiment knob
+    const int b = Cout > 64 ? 128 : (Cout > 32 ? 64 : (Cout > 16 ? 32 : 16));
+    return b > cap ? cap : b;
+}
 
 template <typename T>
 int dispatch_wgrad(const WGradP& p, int splits, hipStream_t s) {
