@@ -1067,7 +1067,7 @@ int pick_tile(long M, int N, int Ktot) {
     // The loop is latency-bound, not MFMA-bound: the 64x64 kernel needs 111 VGPRs and 32 KB of LDS (4 workgroups per CU), the 128x128
     // one 222 VGPRs and 70 KB (2 per CU), and occupancy wins over operand reuse.  SDE_TILE_BIG / SDE_TILE_MID re-open the choice.
     static const int big = [] { const char* e = getenv("SDE_TILE_BIG"); return e ? atoi(e) : 64064; }();       // N > 64:  64064 | 128064 | 128128
-    static const int mid = [] { const char* e = getenv("SDE_TILE_MID"); return e ? atoi(e) : 128064; }();      // 32 < N <= 64: 128064 | 64064
+    static const int mid = [] { const char* e = getenv("SDE_TILE_MID"); return e ? atoi(e) : 64064; }();       // 32 < N <= 64: 128064 | 64064
     (void)Ktot;
     if (N > 64) return big;
     if (N > 32) return (sde_cdiv(M, 128) < 192) ? 64064 : mid;
@@ -1107,7 +1107,8 @@ int g_halo_min_blocks = 192;      // below this many workgroups the 64x64 generi
 long halo_tiles(const Gather& g) { return (long)g.Bn * sde_cdiv(g.OH, HT_H) * sde_cdiv(g.OW, HT_W); }
 // N tile of the halo kernel: 128 wide when that still gives >= 256 workgroups, else 64 (mid-resolution layers), 32 / 16 for narrow outputs
 int halo_bn(const Gather& g, int ldy) {
-    if (ldy > 64) return halo_tiles(g) * sde_cdiv(ldy, 128) >= 256 ? 128 : 64;
+    static const int bn_max = [] { const char* e = getenv("SDE_HALO_BN_MAX"); return e ? atoi(e) : 128; }();     // experiment knob: 64 = narrower tile, 3 waves / SIMD
+    if (ldy > 64) return (bn_max >= 128 && halo_tiles(g) * sde_cdiv(ldy, 128) >= 256) ? 128 : 64;
     return ldy > 32 ? 64 : (ldy > 16 ? 32 : 16);
 }
 bool use_halo(const Gather& g, int dtype, int ldy) {
@@ -1192,7 +1193,9 @@ int dispatch_wsrc(const WGradP& p, int splits, hipStream_t s) {
 }
 
 int wgrad_bmg(int Cout) {
-    static const int cap = [] { const char* e = getenv("SDE_WGRAD_BMG"); const int v = e ? atoi(e) : 0; return v == 64 ? 64 : 128; }();   // experiment knob
+    // 64 x 128 (Cout x K) tiles by default: twice the tiles of 128 x 128, so half the pixel splits / fp32 slabs for the same number of
+    // workgroups (measured 10.03 vs 10.12 ms/step); SDE_WGRAD_BMG=128 restores the wide tile
+    static const int cap = [] { const char* e = getenv("SDE_WGRAD_BMG"); const int v = e ? atoi(e) : 0; return v == 128 ? 128 : 64; }();
     const int b = Cout > 64 ? 128 : (Cout > 32 ? 64 : (Cout > 16 ? 32 : 16));
     return b > cap ? cap : b;
 }
