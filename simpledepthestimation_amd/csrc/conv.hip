@@ -1107,7 +1107,7 @@ int g_halo_min_blocks = 192;      // below this many workgroups the 64x64 generi
 long halo_tiles(const Gather& g) { return (long)g.Bn * sde_cdiv(g.OH, HT_H) * sde_cdiv(g.OW, HT_W); }
 // N tile of the halo kernel: 128 wide when that still gives >= 256 workgroups, else 64 (mid-resolution layers), 32 / 16 for narrow outputs
 int halo_bn(const Gather& g, int ldy) {
-    static const int bn_max = [] { const char* e = getenv("SDE_HALO_BN_MAX"); return e ? atoi(e) : 128; }();     // experiment knob: 64 = narrower tile, 3 waves / SIMD
+    static const int bn_max = [] { const char* e = getenv("SDE_HALO_BN_MAX"); return e ? atoi(e) : 64; }();      // 64: narrower tile, 3 waves / SIMD (measured 10.05 vs 10.10 ms/step); 128 re-opens the wide tile
     if (ldy > 64) return (bn_max >= 128 && halo_tiles(g) * sde_cdiv(ldy, 128) >= 256) ? 128 : 64;
     return ldy > 32 ? 64 : (ldy > 16 ? 32 : 16);
 }
