@@ -140,6 +140,7 @@ def cpu_baseline(args):
     wl = WORKLOADS[args.workload]
     enc = int(wl["enc"])
     B, H, W = args.cpu_batch, args.height, args.width
+    torch.set_num_threads(min(32, os.cpu_count() or 1))      # small-batch CPU convolutions stop scaling (and regress) beyond a few dozen threads
     threads = torch.get_num_threads()
     if wl.get("packnet"):
         sd, enc = OM.init_packnet_state_dict(wl["packnet"][-1], seed=0), "packnet" + wl["packnet"]

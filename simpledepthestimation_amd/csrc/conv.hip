@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
             const int k = s * BK + ac0 * V;
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
-                ra[st][c] = buf_load16(rs0, (an >= 0 && k + c * V < g.Ktot) ? rowoff + (unsigned)(k + c * V) * (unsigned)sizeof(T) : kOOB);
+                ra[st][c] = buf_load16(rs0, (k + c * V < g.Ktot) ? rowoff + (unsigned)(k + c * V) * (unsigned)sizeof(T) : kOOB);   // rowoff is kOOB for rows >= M
         } else if (ONE_TAP) {
             unsigned o0, o1;
             gather_off<T, SRC>(g, an >= 0 && akh < g.KH, an, aih + akh, aiw + akw, aci, o0, o1);
@@ -288,7 +288,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
         for (int i = 0; i < B_PASSES; ++i) {
             const int row = r0 + i * B_ROWS_PER_PASS;
             const int n = n0 + row;
-            const unsigned ow = (kok && row < BN && n < p.Cout) ? (unsigned)(n * g.Ktot + k) * (unsigned)sizeof(T) : kOOB;
+            constexpr bool rows_fit = B_ROWS_PER_PASS * B_PASSES <= BN;        // every pass row is a tile row (BN >= 32): no per-row test
+            const unsigned ow = (kok && (rows_fit || row < BN) && n < p.Cout) ? (unsigned)(n * g.Ktot + k) * (unsigned)sizeof(T) : kOOB;
             rb[st][i] = buf_load16(rsw, ow);
         }
     };
@@ -300,7 +301,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int row = r0 + i * B_ROWS_PER_PASS;
-            if (row < BN) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = rb[st][i];
+            if (B_ROWS_PER_PASS * B_PASSES <= BN || row < BN)
+                *reinterpret_cast<uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = rb[st][i];
         }
     };
 
@@ -529,7 +531,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) halo3_kernel(IGemmP p) {
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int row = r0 + i * B_ROWS_PER_PASS;
-            if (row < BN) *reinterpret_cast<uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = rb[st][i];
+            if (B_ROWS_PER_PASS * B_PASSES <= BN || row < BN)
+                *reinterpret_cast<uint4*>(sB + (size_t)(buf * BN + row) * KSTAGE_BYTES + ((cc ^ (row & 7)) << 4)) = rb[st][i];
         }
     };
 

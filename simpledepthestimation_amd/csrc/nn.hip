@@ -571,24 +571,24 @@ __device__ __forceinline__ void fixed_order_channel_sum(float a1, float a2, int 
     }
 }
 
-// 16-byte variant: thread t walks the channel group t % cch (cch = C / V divides 256); the 256 / cch threads of a group are combined
-// in thread order through LDS.  a1 / a2: the thread's V partial sums each.  sh = [2][C].
+// 16-byte variant: thread t walks the channel group t % cch (cch = C / V, a power of two <= 256); the 256 / cch threads of a group are
+// combined by a fixed binary tree in LDS (deterministic).  a1 / a2: the thread's V partial sums each.  sh = [2][C].
 template <int V>
 __device__ __forceinline__ void fixed_order_group_sum(const float* a1, const float* a2, int cch, float* sh, int C) {
     __shared__ float red[256 * 2 * V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { red[(threadIdx.x * 2) * V + e] = a1[e]; red[(threadIdx.x * 2 + 1) * V + e] = a2[e]; }
     __syncthreads();
-    if ((int)threadIdx.x < cch) {
-        float t1[V], t2[V];
+    // fixed binary tree over the 256 / cch threads of a channel group (threads t and t + s share a group: s is a multiple of cch)
+    for (int s = 128; s >= cch; s >>= 1) {
+        if ((int)threadIdx.x < s)
 #pragma unroll
-        for (int e = 0; e < V; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
-        for (int r = threadIdx.x; r < 256; r += cch)
-#pragma unroll
-            for (int e = 0; e < V; ++e) { t1[e] += red[(r * 2) * V + e]; t2[e] += red[(r * 2 + 1) * V + e]; }
-#pragma unroll
-        for (int e = 0; e < V; ++e) { sh[threadIdx.x * V + e] = t1[e]; sh[C + threadIdx.x * V + e] = t2[e]; }
+            for (int e = 0; e < 2 * V; ++e) red[threadIdx.x * 2 * V + e] += red[(threadIdx.x + s) * 2 * V + e];
+        __syncthreads();
     }
+    if ((int)threadIdx.x < cch)
+#pragma unroll
+        for (int e = 0; e < V; ++e) { sh[threadIdx.x * V + e] = red[(threadIdx.x * 2) * V + e]; sh[C + threadIdx.x * V + e] = red[(threadIdx.x * 2 + 1) * V + e]; }
 }
 
 template <typename T>
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
     const T* base = x + ((long)b * HW + p0) * C;
     float a1 = 0.f, a2 = 0.f;
     constexpr int V = VecOf<T>::V;
-    if (C % V == 0 && 256 % (C / V) == 0) {          // 16 bytes per lane, fixed channel group per thread
+    if (C % V == 0 && 256 % (C / V) == 0) {          // 16 bytes per lane, fixed channel group per thread (256 % cch == 0 => cch is a power of two)
         const int cch = C / V;
         float v1[V], v2[V];
 #pragma unroll
