@@ -5,8 +5,9 @@ run() { # name, env...
   if grep -q "HSA_STATUS" gpurun_out/ab.err; then echo "fault $name"; exit 3; fi
   echo "$WL $name $(python -c "import json;d=json.load(open('gpurun_out/ab.json'));print(d['value'], d['ms_per_step'])")"
 }
-timeout -k 10 600 python -m pytest tests/test_gpu_nn.py -q -m gpu -k "group_norm or conv_fwd_bwd" 2>&1 | tail -3
+timeout -k 10 600 python -m pytest tests/test_gpu_nn.py -q -m gpu -k "group_norm" 2>&1 | tail -3
 WL=mono_r18 run default SDE_X=0
 WL=mono_r18 run default SDE_X=0
-WL=sup_r50 run default SDE_X=0
-WL=sup_r50 run default SDE_X=0
+
+
+timeout -k 10 300 python -m pytest tests/test_gpu_models.py -q -m gpu -k "mono or packnet" 2>&1 | tail -3

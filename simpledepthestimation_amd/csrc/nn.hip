@@ -652,22 +652,30 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
     for (int i = threadIdx.x; i < C; i += 256) { o[i * 2] = sh[i]; o[i * 2 + 1] = sh[C + i]; }
 }
 
-// gnp [B][G][2] = mean, rstd
+__device__ __forceinline__ double wave_sum_f64(double v) {       // fixed butterfly order: deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// gnp [B][G][2] = mean, rstd.  One wave per (sample, group): the lanes split the GN_CHUNKS x cpg partials.
 __global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict__ part, int B, int C, int G, int HW, float eps, float* __restrict__ gnp) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= B * G) return;
+    const int i = blockIdx.x;                    // (b, g)
     const int b = i / G, gidx = i % G, cpg = C / G;
     double s1 = 0, s2 = 0;
-    for (int ch = 0; ch < GN_CHUNKS; ++ch)
-        for (int c = gidx * cpg; c < (gidx + 1) * cpg; ++c) {
-            s1 += part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2];
-            s2 += part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2 + 1];
-        }
-    const double n = (double)HW * cpg, mean = s1 / n;
-    double var = s2 / n - mean * mean;
-    if (var < 0) var = 0;
-    gnp[i * 2] = (float)mean;
-    gnp[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int q = threadIdx.x; q < GN_CHUNKS * cpg; q += 64) {
+        const int ch = q / cpg, c = gidx * cpg + q % cpg;
+        s1 += part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2];
+        s2 += part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2 + 1];
+    }
+    s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+    if (threadIdx.x == 0) {
+        const double n = (double)HW * cpg, mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        if (var < 0) var = 0;
+        gnp[i * 2] = (float)mean;
+        gnp[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 template <typename T>
@@ -772,32 +780,36 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
     for (int i = threadIdx.x; i < C; i += 256) { o[i * 2] = sh[i]; o[i * 2 + 1] = sh[C + i]; }
 }
 
-// per (b, g): m1 = mean_g(gamma*dz), m2 = mean_g(gamma*dz*xhat); per channel: dgamma = sum_b sum dz*xhat, dbeta = sum_b sum dz
+// blocks [0, B*G): per (b, g) m1 = mean_g(gamma*dz), m2 = mean_g(gamma*dz*xhat); blocks [B*G, B*G + C): per channel
+// dgamma = sum_b sum dz*xhat, dbeta = sum_b sum dz.  One wave each, lanes split the partials.
 __global__ void __launch_bounds__(64) gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int B, int C, int G, int HW,
                                                              float* __restrict__ coef /*[B][G][2]*/, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              int accumulate) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
     const int cpg = C / G;
-    if (i < B * G) {
-        const int b = i / G, gidx = i % G;
-        double s1 = 0, s2 = 0;
-        for (int ch = 0; ch < GN_CHUNKS; ++ch)
-            for (int c = gidx * cpg; c < (gidx + 1) * cpg; ++c) {
-                s1 += (double)gamma[c] * part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2];
-                s2 += (double)gamma[c] * part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2 + 1];
-            }
-        const double n = (double)HW * cpg;
-        coef[i * 2] = (float)(s1 / n); coef[i * 2 + 1] = (float)(s2 / n);
-    }
-    if (i < C) {
-        double s1 = 0, s2 = 0;
-        for (int b = 0; b < B; ++b)
-            for (int ch = 0; ch < GN_CHUNKS; ++ch) {
-                s1 += part[(((size_t)b * GN_CHUNKS + ch) * C + i) * 2];
-                s2 += part[(((size_t)b * GN_CHUNKS + ch) * C + i) * 2 + 1];
-            }
-        dgamma[i] = accumulate ? dgamma[i] + (float)s2 : (float)s2;
-        dbeta[i] = accumulate ? dbeta[i] + (float)s1 : (float)s1;
+    double s1 = 0, s2 = 0;
+    if ((int)blockIdx.x < B * G) {
+        const int i = blockIdx.x, b = i / G, gidx = i % G;
+        for (int q = threadIdx.x; q < GN_CHUNKS * cpg; q += 64) {
+            const int ch = q / cpg, c = gidx * cpg + q % cpg;
+            s1 += (double)gamma[c] * part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2];
+            s2 += (double)gamma[c] * part[(((size_t)b * GN_CHUNKS + ch) * C + c) * 2 + 1];
+        }
+        s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+        if (threadIdx.x == 0) {
+            const double n = (double)HW * cpg;
+            coef[i * 2] = (float)(s1 / n); coef[i * 2 + 1] = (float)(s2 / n);
+        }
+    } else {
+        const int c = blockIdx.x - B * G;
+        for (int q = threadIdx.x; q < B * GN_CHUNKS; q += 64) {
+            s1 += part[((size_t)q * C + c) * 2];               // q = b * GN_CHUNKS + ch
+            s2 += part[((size_t)q * C + c) * 2 + 1];
+        }
+        s1 = wave_sum_f64(s1); s2 = wave_sum_f64(s2);
+        if (threadIdx.x == 0) {
+            dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+            dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        }
     }
 }
 
@@ -1047,7 +1059,7 @@ int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B,
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)x, HW, C, part),
                hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)x, HW, C, part));
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/stats");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(sde_cdiv(B * G, 64)), dim3(64), 0, s, part, B, C, G, HW, eps, gnp);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, s, part, B, C, G, HW, eps, gnp);
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/finalize");
     const int nb = grid_for((long)B * HW * (C / (dtype == SDE_BF16 ? 8 : 4)));
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, gnp, gamma, beta, B, HW, C, G, relu, (float*)out),
@@ -1066,8 +1078,7 @@ int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const floa
                hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)x, gnp, HW, C, G, relu, part),
                hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, HW, C, G, relu, part));
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/stats");
-    const int n = B * G > C ? B * G : C;
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(sde_cdiv(n, 64)), dim3(64), 0, s, part, gamma, B, C, G, HW, coef, dgamma, dbeta, accumulate_params);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * G + C), dim3(64), 0, s, part, gamma, B, C, G, HW, coef, dgamma, dbeta, accumulate_params);
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/finalize");
     const int nb = grid_for((long)B * HW * (C / (dtype == SDE_BF16 ? 8 : 4)));
     DISPATCH_T(dtype,
