@@ -488,15 +488,28 @@ __global__ void __launch_bounds__(FT_N) photo_bwd_kernel(PhotoBwdArgs a) {
 __global__ void pose_grad_finalize_kernel(const float* __restrict__ partial, int blocks_per_sample, int nctx, int B,
                                           float* __restrict__ dpose0, float* __restrict__ dpose1, float* __restrict__ dpose2,
                                           float* __restrict__ dpose3, int accumulate) {
-    const int b = blockIdx.x, j = blockIdx.y, i = threadIdx.x;   // i < 12
-    if (i >= 12) return;
-    float s = 0.f;
-    for (int k = 0; k < blocks_per_sample; ++k) s += partial[(((long)b * blocks_per_sample + k) * nctx + j) * 12 + i];
+    // one wave per (sample, context): the lanes split the per-workgroup partials, then a fixed butterfly per output (deterministic)
+    const int b = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int k = lane; k < blocks_per_sample; k += 64) {
+        const float* p = partial + (((long)b * blocks_per_sample + k) * nctx + j) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] += p[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = sde_wave_sum(acc[i]);
     float* dp = j == 0 ? dpose0 : (j == 1 ? dpose1 : (j == 2 ? dpose2 : dpose3));
-    const int r = i < 9 ? i / 3 : i - 9, c = i < 9 ? i % 3 : 3;
-    float* o = dp + b * 16 + r * 4 + c;
-    *o = accumulate ? (*o + s) : s;
-    if (!accumulate && i < 4) dp[b * 16 + 12 + i] = 0.f;
+    if (lane < 12) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s = lane == i ? acc[i] : s;
+        const int r = lane < 9 ? lane / 3 : lane - 9, c = lane < 9 ? lane % 3 : 3;
+        float* o = dp + b * 16 + r * 4 + c;
+        *o = accumulate ? (*o + s) : s;
+        if (!accumulate && lane < 4) dp[b * 16 + 12 + lane] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
