@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
-timeout -k 10 300 python -m pytest tests/test_gpu_photometric.py tests/test_gpu_models.py -q -m gpu -k "photo or mono or pose" 2>&1 | tail -3
-bash scripts/gpu_profile_packnet.sh
-WL=mono_r18; timeout -k 10 200 python bench.py --workload mono_r18 --steps 30 --warmup 5 --no-cpu-baseline --profile-steps 0 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('mono_r18', d['value'], d['ms_per_step'])"
+timeout -k 10 300 python -m pytest tests/test_gpu_nn.py -q -m gpu -k "conv3d" 2>&1 | tail -2
+bash scripts/gpu_profile_packnet.sh 2>&1 | grep -E "rc=|conv3d|igemm_kernelIDF16bLi64ELi64ELi2ELi2ELi0ELb1|wgrad_kernelIDF16bLi64ELi128ELi1ELi4ELi0ELb1" | cut -c1-200
+bash scripts/gpu_profile.sh r1e > gpurun_out/prof/r1e.log 2>&1; tail -60 gpurun_out/prof/r1e.log | cut -c1-220

@@ -143,26 +143,33 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const T* __restrict__
 
 // part[block][f*28 + t] (t < 27: weight tap, t == 27: bias) = this workgroup's share of
 //   dw[f][kd][kh][kw] = sum dy[b,h,w,f*D+ch] * x[b,h+kh-1,w+kw-1,ch+kd-1] ;  dbias[f] = sum dy[b,h,w,f*D+ch]
-constexpr int WG_ITEMS = 4;      // (pixel, channel group) items per thread
+constexpr int WG_ITEMS = 8;      // (pixel, channel group) items per thread
+constexpr int WG_F = 2;          // features per pass: the 3x3 neighbourhood is re-read NF / WG_F times (registers: WG_F x 28 sums + 10 taps)
 template <typename T>
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, int B, int H,
                                                            int W, int D) {
     constexpr int V = VecOf<T>::V;
-    __shared__ float red[4][NT + 1];
+    __shared__ float red[4][WG_F][NT + 1];
     const long total = (long)B * H * W * (D / V);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int f = 0; f < NF; ++f) {
-        float acc[NT + 1];
+    for (int f0 = 0; f0 < NF; f0 += WG_F) {
+        float acc[WG_F][NT + 1];
 #pragma unroll
-        for (int t = 0; t <= NT; ++t) acc[t] = 0.f;
+        for (int f = 0; f < WG_F; ++f)
+#pragma unroll
+            for (int t = 0; t <= NT; ++t) acc[f][t] = 0.f;
+#pragma unroll 1
         for (int i = 0; i < WG_ITEMS; ++i) {
             const long idx = ((long)blockIdx.x * WG_ITEMS + i) * 256 + threadIdx.x;
             if (idx >= total) break;
             const Item it = decode<V>(idx, H, W, D);
-            float g[V];
-            load_vec<T>(dy + it.pix * ((long)NF * D) + (long)f * D + it.c0, g);
+            float g[WG_F][V];
 #pragma unroll
-            for (int c = 0; c < V; ++c) acc[NT] += g[c];
+            for (int f = 0; f < WG_F; ++f) {
+                load_vec<T>(dy + it.pix * ((long)NF * D) + (long)(f0 + f) * D + it.c0, g[f]);
+#pragma unroll
+                for (int c = 0; c < V; ++c) acc[f][NT] += g[f][c];
+            }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const int iy = it.y + kh - 1;
@@ -174,24 +181,32 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const T* __restrict__
                     float xv[V + 2];
                     load_with_edges<T>(x + (((long)it.b * H + iy) * W + ix) * D + it.c0, it.c0, D, xv);
 #pragma unroll
-                    for (int kd = 0; kd < 3; ++kd) {
-                        float s = 0.f;
+                    for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-                        for (int c = 0; c < V; ++c) s = fmaf(g[c], xv[c + kd], s);
-                        acc[kd * 9 + kh * 3 + kw] += s;
-                    }
+                        for (int f = 0; f < WG_F; ++f) {           // WG_F x 3 independent chains per tap
+                            float s = 0.f;
+#pragma unroll
+                            for (int c = 0; c < V; ++c) s = fmaf(g[f][c], xv[c + kd], s);
+                            acc[f][kd * 9 + kh * 3 + kw] += s;
+                        }
                 }
             }
         }
 #pragma unroll
-        for (int t = 0; t <= NT; ++t) acc[t] = sde_wave_sum(acc[t]);
-        __syncthreads();       // previous feature's readers are done with red[]
+        for (int f = 0; f < WG_F; ++f)
+#pragma unroll
+            for (int t = 0; t <= NT; ++t) acc[f][t] = sde_wave_sum(acc[f][t]);
+        __syncthreads();       // previous pass's readers are done with red[]
         if (lane == 0)
 #pragma unroll
-            for (int t = 0; t <= NT; ++t) red[wave][t] = acc[t];
+            for (int f = 0; f < WG_F; ++f)
+#pragma unroll
+                for (int t = 0; t <= NT; ++t) red[wave][f][t] = acc[f][t];
         __syncthreads();
-        if (threadIdx.x <= NT)
-            part[(size_t)blockIdx.x * WG_COLS + f * (NT + 1) + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (threadIdx.x < WG_F * (NT + 1)) {
+            const int f = threadIdx.x / (NT + 1), t = threadIdx.x % (NT + 1);
+            part[(size_t)blockIdx.x * WG_COLS + (f0 + f) * (NT + 1) + t] = (red[0][f][t] + red[1][f][t]) + (red[2][f][t] + red[3][f][t]);
+        }
     }
 }
 
