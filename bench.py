@@ -72,7 +72,7 @@ def build(args, device):
     return cfg, model, trainer
 
 
-def roofline_pass(trainer, batch, steps, dtype):
+def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50"):
     """Event-instrumented eager steps of the same workload: per GEMM launch (kind, tile variant) duration and algorithmic FLOPs."""
     from simpledepthestimation_amd.hip import lib as L
     def one():
@@ -126,12 +126,46 @@ def roofline_pass(trainer, batch, steps, dtype):
         name = f"halo3_kernel<{dtype},8x16 pixels x {dom_key[1] % 1000}>"
     else:
         name = f"igemm_kernel<{dtype},{dom_key[1] // 1000}x{dom_key[1] % 1000}>"
-    return hbm, {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+    traffic, traffic_src = pmc_traffic(dom_key, dtype) if workload == "sup_r50" else (None, None)      # the committed counter passes are of that workload
+    return hbm, {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_source": traffic_src,
             "kernel": name, "launches_per_step": dom["launches"] // steps, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
             "gemm_flops_per_step": tot_fl / steps, "gemm_ms_per_step": round(tot_ms / steps, 3),
             "all_gemm_achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
             "families": {f"{k[0]}:{k[1]}": {"ms_per_step": round(v["ms"] / steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                             "launches_per_step": v["launches"] // steps} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+
+
+def pmc_traffic(dom_key, dtype):
+    """HBM bytes per launch of the dominant kernel family from the committed counter passes of the same command (scripts/gpu_profile.sh:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, kernel-trace only; FETCH_SIZE doubled for 16-byte-per-lane reads as
+    MI355X_MICROARCH.md prescribes; KB -> bytes).  None when no matching profile is committed (e.g. other dtype / workload)."""
+    import csv
+    import glob
+    if dtype != "bf16":
+        return None, None
+    kind, variant = dom_key
+    if kind == "igemm":
+        pat = "halo3_kernel" if variant >= 3000000 else f"igemm_kernelIDF16bLi{variant // 1000}ELi{variant % 1000}E"
+    elif kind == "wgrad":
+        pat = "wgrad_kernelIDF16b"
+    else:
+        return None, None
+    fetch = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fetch_by_kernel.csv")))
+    write = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_write_by_kernel.csv")))
+    if not fetch or not write:
+        return None, None
+
+    def per_launch(path):
+        tot, n = 0.0, 0
+        for r in csv.DictReader(open(path)):
+            if pat in r["kernel"]:
+                tot += float(r["sum"]); n += int(r["launches"])
+        return tot / n if n else None
+    f, w = per_launch(fetch[-1]), per_launch(write[-1])
+    if f is None or w is None:
+        return None, None
+    return int((2.0 * f + w) * 1024), f"{os.path.basename(fetch[-1])} + {os.path.basename(write[-1])} (committed rocprofv3 --pmc passes, Supervised-R50 workload)"
 
 
 def cpu_baseline(args):
@@ -242,7 +276,7 @@ def main():
                           "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "allreduce_overlap": bool(trainer.overlap)},
                "final_losses": final}
         if args.profile_steps > 0:
-            hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype)
+            hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype, args.workload)
             if hbm is not None:
                 out["roofline_photometric"] = hbm        # MonoDepth2 workloads: the HBM-bound warp+SSIM kernel next to the dominant GEMM
         if not args.no_cpu_baseline:
