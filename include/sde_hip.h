@@ -151,6 +151,11 @@ int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total_b
  * stats (optional): [sde_conv_fwd_tiles_m + SDE_REDUCE_ROWS][Cout][2] per-tile (sum, sum of squares) of the stored outputs, for BatchNorm. */
 int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
                  sde_stream_t stream);
+/* The same with a caller-owned fp32 workspace of sde_conv_fwd_ws_bytes() bytes (0: not needed): small-M, long-K layers then run split-K
+ * (K cut into up to 8 ranges, partial tiles summed in a fixed order by a finishing kernel that also applies bias / activation / statistics). */
+size_t sde_conv_fwd_ws_bytes(const sde_conv_desc* d, int ldy);
+int sde_conv_fwd_ws(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats, void* ws,
+                    size_t ws_bytes, sde_stream_t stream);
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy);
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy);
 /* Tuning / test knob: the LDS-halo 3x3 kernel is used when a launch has at least this many workgroups (default 192; 0 = whenever it

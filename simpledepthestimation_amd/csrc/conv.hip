@@ -117,6 +117,8 @@ struct IGemmP {
     void* y;              // [M][ldy]
     float* stats;         // [tiles_m][Cout][2] or null
     int Cout, ldy, act;
+    int ksplit;           // > 1: the K loop is cut into ksplit ranges, each workgroup writes its raw fp32 tile to ws[split][M][ldy]
+    float* ws;            //      and splitk_finish_kernel sums them in a fixed order and applies bias / activation / statistics
 };
 
 constexpr int KSTAGE_BYTES = 128;   // K bytes per row per pipeline stage (2 MFMA sub-blocks of 64 B)
@@ -204,7 +206,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.ldy + BN - 1) / BN;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int logical_all = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_all = gridDim.x / p.ksplit;
+    const int split = logical_all / tiles_all, logical = logical_all - split * tiles_all;     // the splits of a tile land on different XCDs: no sharing assumed
     const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;     // N tiles of one M tile are adjacent in time, on one XCD
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -221,15 +225,18 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
             aih = oh * g.stride - g.pad; aiw = ow * g.stride - g.pad;
         }
     }
+    const int nk_total = (g.Ktot + BK - 1) / BK;
+    const int nk_per = (nk_total + p.ksplit - 1) / p.ksplit;
+    const int s_begin = split * nk_per;                                 // this workgroup's K stages: [s_begin, s_begin + nk)
     int aci, akh, akw;     // position of chunk ac0 of the NEXT stage to load
     {
-        const int k = ac0 * V;
+        const int k = s_begin * BK + ac0 * V;
         const int tap = k / g.Cin;
         aci = k - tap * g.Cin; akh = tap / g.KW; akw = tap - akh * g.KW;
     }
     // ---- B side (weights, plain 2-D): rows r0 + 32 i, chunk column cc
     const int cc = tid & 7, r0 = tid >> 3;
-    const int nk = (g.Ktot + BK - 1) / BK;
+    const int nk = max(0, min(nk_total, s_begin + nk_per) - s_begin);
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(g.x0, (long)g.Bn * g.H0 * g.W0 * g.C0 * (long)sizeof(T));
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1 ? g.x1 : g.x0, g.x1 ? (long)g.Bn * g.IH * g.IW * g.C1 * (long)sizeof(T) : 0);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (long)p.Cout * g.Ktot * (long)sizeof(T));
@@ -246,7 +253,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
     auto load_stage = [&](int s, auto SET) {
         constexpr int st = decltype(SET)::value;
         if (SRC == SRC_1X1) {
-            const int k = s * BK + ac0 * V;
+            const int k = (s_begin + s) * BK + ac0 * V;
 #pragma unroll
             for (int c = 0; c < CPT; ++c)
                 ra[st][c] = buf_load16(rs0, (k + c * V < g.Ktot) ? rowoff + (unsigned)(k + c * V) * (unsigned)sizeof(T) : kOOB);   // rowoff is kOOB for rows >= M
@@ -282,7 +289,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
             aci += BK;
             while (aci >= g.Cin) { aci -= g.Cin; if (++akw == g.KW) { akw = 0; ++akh; } }
         }
-        const int k = s * BK + cc * V;
+        const int k = (s_begin + s) * BK + cc * V;
         const bool kok = k < g.Ktot;
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
@@ -343,10 +350,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
         if (st + 1 < nk) store_stage((st + 1) & 1, NXT);
         __syncthreads();
     };
-    load_stage(0, IC<0>{});
+    if (nk > 0) load_stage(0, IC<0>{});
     if (nk > 1) load_stage(1, IC<1>{});
     if (nk > 2) load_stage(2, IC<2>{});
-    store_stage(0, IC<0>{});
+    if (nk > 0) store_stage(0, IC<0>{});
     __syncthreads();
     for (int s = 0; s < nk; s += 3) {
         step(s, IC<0>{}, IC<1>{});
@@ -370,6 +377,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
     // consecutive 4-element groups of the NHWC row (a wave instruction covers whole 128-byte lines)
     constexpr int G4 = BN / 4;
     const bool vec_ok = (p.ldy % 4) == 0;
+    if (p.ksplit > 1) {       // raw fp32 partial tile; bias / activation / statistics happen in splitk_finish_kernel
+        float* wsp = p.ws + (size_t)split * g.M * p.ldy;
+        for (int id = tid; id < BM * G4; id += NTHREADS) {
+            const int row = id / G4, c0 = (id - row * G4) * 4;
+            const int m = m0 + row, n = n0 + c0;
+            if (m >= g.M || n >= p.ldy) continue;
+            *reinterpret_cast<float4*>(wsp + (size_t)m * p.ldy + n) = *reinterpret_cast<const float4*>(&sC[row * (BN + CPAD) + c0]);     // ldy % 4 == 0
+        }
+        return;
+    }
     for (int id = tid; id < BM * G4; id += NTHREADS) {
         const int row = id / G4, c0 = (id - row * G4) * 4;
         const int m = m0 + row, n = n0 + c0;
@@ -417,6 +434,56 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
             p.stats[((size_t)tile_m * p.Cout + n0 + tid) * 2 + 0] = a;
             p.stats[((size_t)tile_m * p.Cout + n0 + tid) * 2 + 1] = b;
         }
+    }
+}
+
+// Split-K finish: y[m][n] = act(sum_s ws[s][m][n] + bias[n]) in a fixed order, padded channels zero, plus the per-64-row-tile column
+// sums BatchNorm needs (same slab layout as the fused epilogue of the 64x64 tile).  One workgroup = 64 rows x 64 columns.
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const float* __restrict__ ws, int S, int M, int ldy, int Cout, const float* __restrict__ bias,
+                                                            int act, T* __restrict__ y, float* __restrict__ stats) {
+    __shared__ float red[16][64][2];
+    const int tiles_n = (ldy + 63) / 64;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int c0 = tile_n * 64 + (threadIdx.x & 15) * 4, rg = threadIdx.x >> 4;     // 16 column groups of 4, 16 row groups
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < ldy) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = tile_m * 64 + rg + 16 * i;
+            if (m >= M) continue;
+            float4 a = *reinterpret_cast<const float4*>(ws + (size_t)m * ldy + c0);
+            for (int sp = 1; sp < S; ++sp) {
+                const float4 b = *reinterpret_cast<const float4*>(ws + ((size_t)sp * M + m) * ldy + c0);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            float v[4] = {a.x, a.y, a.z, a.w};
+            T o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[e];
+                if (bias && c0 + e < Cout) t += bias[c0 + e];
+                if (act == SDE_ACT_ELU) t = t > 0.f ? t : expm1f(t);
+                if (c0 + e >= Cout) t = 0.f;
+                o[e] = from_f32<T>(t);
+                const float r = to_f32<T>(o[e]);         // statistics of the stored (rounded) values, as in the fused epilogue
+                s1[e] += r; s2[e] += r * r;
+            }
+            T* dst = y + (size_t)m * ldy + c0;
+            if (sizeof(T) == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(o);
+            else *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(o);
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[rg][(threadIdx.x & 15) * 4 + e][0] = s1[e]; red[rg][(threadIdx.x & 15) * 4 + e][1] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64 && tile_n * 64 + threadIdx.x < Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a += red[q][threadIdx.x][0]; b += red[q][threadIdx.x][1]; }
+        stats[((size_t)tile_m * Cout + tile_n * 64 + threadIdx.x) * 2 + 0] = a;
+        stats[((size_t)tile_m * Cout + tile_n * 64 + threadIdx.x) * 2 + 1] = b;
     }
 }
 
@@ -1058,7 +1125,7 @@ int launch_igemm(const IGemmP& p, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, WM, WN, SRC, ONE_TAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    dim3 grid(sde_cdiv(p.g.M, BM) * sde_cdiv(p.ldy, BN));
+    dim3 grid(sde_cdiv(p.g.M, BM) * sde_cdiv(p.ldy, BN) * p.ksplit);
     hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, SRC, ONE_TAP>), grid, dim3(NTHREADS), lds, s, p);
     return 0;
 }
@@ -1240,22 +1307,63 @@ int fill_gather(const sde_conv_desc* d, Gather& g, const char* who) {
 
 extern "C" {
 
-int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
-                 sde_stream_t stream) {
+// Split-K factor of a forward / data-gradient GEMM: layers whose 64x64 tiling leaves most of the 256 CUs x 4 workgroup slots empty while
+// the K loop is long (layer4 and the first decoder levels: M = 1440 ... 5760 pixels) cut K into up to 8 ranges.
+static int pick_ksplit(const Gather& g, int dtype, int ldy) {
+    static const int off = [] { const char* e = getenv("SDE_NO_SPLITK"); return e ? atoi(e) : 0; }();
+    if (off || use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064 || ldy % 4) return 1;
+    const long tiles = (long)sde_cdiv(g.M, 64) * sde_cdiv(ldy, 64);
+    const int nk = sde_cdiv(g.Ktot, dtype == SDE_BF16 ? 64 : 32);
+    if (tiles >= 384 || nk < 16) return 1;
+    long S = sde_cdiv(768, tiles);
+    if (S > 8) S = 8;
+    if (S > nk / 8) S = nk / 8;
+    return S < 2 ? 1 : (int)S;
+}
+
+static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
+                         float* ws, size_t ws_bytes, sde_stream_t stream) {
     SDE_CHECK_ARG(d && w_packed && y, "sde_conv_fwd: null pointer");
     IGemmP p;
     int rc = fill_gather(d, p.g, "sde_conv_fwd");
     if (rc) return rc;
-    const int V = d->dtype == SDE_BF16 ? 8 : 4;
     SDE_CHECK_ARG(Cout > 0 && ldy >= Cout, "sde_conv_fwd: bad Cout=%d ldy=%d", Cout, ldy);
     SDE_CHECK_ARG(act == SDE_ACT_NONE || act == SDE_ACT_ELU, "sde_conv_fwd: bad act %d", act);
-    (void)V;
     p.w = w_packed; p.bias = bias; p.y = y; p.stats = stats; p.Cout = Cout; p.ldy = ldy; p.act = act;
+    p.ksplit = 1; p.ws = nullptr;
+    const int S = ws ? pick_ksplit(p.g, d->dtype, ldy) : 1;
+    if (S > 1) {
+        SDE_CHECK_ARG(ws_bytes >= (size_t)S * p.g.M * ldy * sizeof(float), "sde_conv_fwd_ws: workspace too small (%zu bytes)", ws_bytes);
+        p.ksplit = S; p.ws = ws;
+    }
     if (use_halo(p.g, d->dtype, ldy)) dispatch_halo(p, (hipStream_t)stream);
     else if (d->dtype == SDE_BF16) dispatch_igemm<bf16_t>(p, (hipStream_t)stream);
     else dispatch_igemm<float>(p, (hipStream_t)stream);
     SDE_CHECK_LAUNCH("sde_conv_fwd");
+    if (S > 1) {
+        const unsigned nb = (unsigned)(sde_cdiv(p.g.M, 64) * sde_cdiv(ldy, 64));
+        if (d->dtype == SDE_BF16) hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, ws, S, p.g.M, ldy, Cout, bias, act, (bf16_t*)y, stats);
+        else hipLaunchKernelGGL(splitk_finish_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, ws, S, p.g.M, ldy, Cout, bias, act, (float*)y, stats);
+        SDE_CHECK_LAUNCH("sde_conv_fwd/splitk_finish");
+    }
     return SDE_OK;
+}
+
+int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
+                 sde_stream_t stream) {
+    return conv_fwd_impl(d, w_packed, bias, act, y, Cout, ldy, stats, nullptr, 0, stream);
+}
+
+size_t sde_conv_fwd_ws_bytes(const sde_conv_desc* d, int ldy) {
+    Gather g;
+    if (!d || fill_gather(d, g, "sde_conv_fwd_ws_bytes") != SDE_OK) return 0;
+    const int S = pick_ksplit(g, d->dtype, ldy);
+    return S > 1 ? (size_t)S * g.M * ldy * sizeof(float) : 0;
+}
+
+int sde_conv_fwd_ws(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats, void* ws,
+                    size_t ws_bytes, sde_stream_t stream) {
+    return conv_fwd_impl(d, w_packed, bias, act, y, Cout, ldy, stats, (float*)ws, ws_bytes, stream);
 }
 
 static int gather_of(const sde_conv_desc* d, Gather& g) { return fill_gather(d, g, "sde_conv_fwd_tiles_m"); }

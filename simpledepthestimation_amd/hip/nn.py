@@ -29,6 +29,8 @@ L.register_protos({
     "sde_pack_item_blocks": ([_I, _I, _I, _I], c_int),
     "sde_conv_fwd": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P], c_int),
     "sde_conv_fwd_tiles_m": ([POINTER(ConvDesc), _I], c_int),
+    "sde_conv_fwd_ws_bytes": ([POINTER(ConvDesc), _I], ctypes.c_size_t),
+    "sde_conv_fwd_ws": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P, ctypes.c_size_t, _P], c_int),
     "sde_conv_fwd_variant": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_set_halo_min_blocks": ([_I], c_int),
     "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
@@ -128,8 +130,10 @@ def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device, kin
         esz = 2 if x_dtype == torch.bfloat16 else 4
         meta = dict(M=d.Bn * d.OH * d.OW, N=ldy, K=d.KH * d.KW * (d.C0 + d.C1), k=d.KH, s=d.stride, mode=d.src_mode,
                     bytes=esz * (d.Bn * d.H0 * d.W0 * d.C0 + d.Bn * d.IH * d.IW * d.C1 + d.Bn * d.OH * d.OW * ldy))
-    _timed(kind, flops, variant, lambda: L.check(lib.sde_conv_fwd(ctypes.byref(d), L.ptr(w_packed), L.ptr(bias), act, L.ptr(y), Cout, ldy, L.ptr(stats),
-                                                                  L.stream()), "sde_conv_fwd"), meta)
+    ws_bytes = lib.sde_conv_fwd_ws_bytes(ctypes.byref(d), ldy)           # > 0: small-M, long-K layer that runs split-K
+    ws = torch.empty(ws_bytes // 4, device=device, dtype=torch.float32) if ws_bytes else None
+    _timed(kind, flops, variant, lambda: L.check(lib.sde_conv_fwd_ws(ctypes.byref(d), L.ptr(w_packed), L.ptr(bias), act, L.ptr(y), Cout, ldy, L.ptr(stats),
+                                                                     L.ptr(ws), ws_bytes, L.stream()), "sde_conv_fwd_ws"), meta)
     return y, stats
 
 
