@@ -1,14 +1,12 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -6 > gpurun_out/gpu_tests_tail.log; cat gpurun_out/gpu_tests_tail.log
-if grep -q "HSA_STATUS_ERROR\|Aborted\|dumped core\|Fatal Python error\|failed" gpurun_out/gpu_tests_tail.log; then echo "stop"; exit 3; fi
 run() { name=$1; shift
   env "$@" timeout -k 10 200 python bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline --profile-steps 0 > gpurun_out/ab.json 2> gpurun_out/ab.err || { echo "failed $name"; tail -3 gpurun_out/ab.err; exit 1; }
   if grep -q "HSA_STATUS" gpurun_out/ab.err; then echo "fault $name"; exit 3; fi
   echo "$WL $name $(python -c "import json;d=json.load(open('gpurun_out/ab.json'));print(d['value'], d['ms_per_step'])")"
 }
-WL=sup_r50 run splitk SDE_X=0
-WL=sup_r50 run nosplitk SDE_NO_SPLITK=1
-WL=sup_r50 run splitk SDE_X=0
-WL=sup_r50 run nosplitk SDE_NO_SPLITK=1
-WL=mono_r18 run splitk SDE_X=0
-WL=mono_r18 run nosplitk SDE_NO_SPLITK=1
+WL=sup_r50 run t384_768 SDE_X=0
+WL=sup_r50 run t512_1024 SDE_SPLITK_TILES=512 SDE_SPLITK_TARGET=1024
+WL=sup_r50 run t768_1536 SDE_SPLITK_TILES=768 SDE_SPLITK_TARGET=1536
+WL=sup_r50 run t1024_2048 SDE_SPLITK_TILES=1024 SDE_SPLITK_TARGET=2048
+WL=sup_r50 run t256_512 SDE_SPLITK_TILES=256 SDE_SPLITK_TARGET=512
+WL=sup_r50 run t384_768 SDE_X=0

@@ -1314,8 +1314,10 @@ static int pick_ksplit(const Gather& g, int dtype, int ldy) {
     if (off || use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064 || ldy % 4) return 1;
     const long tiles = (long)sde_cdiv(g.M, 64) * sde_cdiv(ldy, 64);
     const int nk = sde_cdiv(g.Ktot, dtype == SDE_BF16 ? 64 : 32);
-    if (tiles >= 384 || nk < 16) return 1;
-    long S = sde_cdiv(768, tiles);
+    static const long tmax = [] { const char* e = getenv("SDE_SPLITK_TILES"); return e ? atol(e) : 384L; }();      // split when fewer tiles than this ...
+    static const long target = [] { const char* e = getenv("SDE_SPLITK_TARGET"); return e ? atol(e) : 768L; }();  // ... aiming at this many workgroups
+    if (tiles >= tmax || nk < 16) return 1;
+    long S = sde_cdiv(target, tiles);
     if (S > 8) S = 8;
     if (S > nk / 8) S = nk / 8;
     return S < 2 ? 1 : (int)S;
