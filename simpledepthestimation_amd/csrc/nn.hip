@@ -863,9 +863,10 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 // If the slab has more than SDE_REDUCE_ROWS rows, fold it into SDE_REDUCE_ROWS rows stored right behind it (the caller
 // allocates rows + SDE_REDUCE_ROWS rows).  Returns the pointer / row count the finalize kernel should read.
 const float* pre_reduce(const float* part, int& rows, int width, hipStream_t s) {
-    // the finalize kernels read rows with 32 independent lanes, so slabs up to 2048 rows (64 loads per lane; the 64-row tiles of
-    // layer1 give 1440) need no extra launch
-    if (rows <= 2048) return part;
+    // the finalize kernels read rows with 32 independent lanes, so slabs up to SDE_PRE_REDUCE_ROWS rows (default 512: 16 loads per lane) need
+    // no extra launch; 2048 measured slower (the 64 serial loads per lane cost more than the extra launch)
+    static const int thr = [] { const char* e = getenv("SDE_PRE_REDUCE_ROWS"); return e ? atoi(e) : 512; }();
+    if (rows <= thr) return part;
     float* out = const_cast<float*>(part) + (size_t)rows * width;
     const int chunk = (rows + SDE_REDUCE_ROWS - 1) / SDE_REDUCE_ROWS;
     const int rows_out = (rows + chunk - 1) / chunk;
