@@ -728,6 +728,7 @@ struct WGradP {
     const void* dy;   // [M][ldd]
     float* slab;      // [splits][Cout][Ktot]
     int Cout, ldd, rows_per_split;
+    int single_buf;   // one LDS stage buffer instead of two (see wgrad_kernel)
 };
 
 template <typename T> struct WGTraits;
@@ -777,7 +778,7 @@ template <> struct TrRead<float> {
 };
 
 template <typename T, int BMG, int BNG, int WM, int WN, int SRC, bool ONE_TAP>
-__global__ void __launch_bounds__(NTHREADS, 2) wgrad_kernel(WGradP p) {
+__global__ void __launch_bounds__(NTHREADS, (BMG <= 64 && sizeof(T) == 2) ? 3 : 2) wgrad_kernel(WGradP p) {
     constexpr int V = VecOf<T>::V;
     constexpr int BR = WGTraits<T>::BR;
     constexpr int SUBP = 64 / (int)sizeof(T);          // pixels per MFMA sub-block (32 bf16 / 16 f32)
@@ -797,8 +798,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_kernel(WGradP p) {
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BCH % TPP == 0, "B tile chunking");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;                          // [2][BR][STRA]
-    unsigned char* sB = smem + 2 * BR * STRA;          // [2][BR][STRB]
+    unsigned char* sA = smem;                                          // [nbuf][BR][STRA]
+    unsigned char* sB = smem + (p.single_buf ? 1 : 2) * BR * STRA;     // [nbuf][BR][STRB]
 
     const Gather& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -915,11 +916,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_kernel(WGradP p) {
                 for (int j = 0; j < FN; ++j) acc[i][j] = mma64<T>(a[i], b[j], acc[i][j]);
         }
     };
+    // p.single_buf: one LDS stage buffer instead of two (half the LDS -> one more workgroup per CU for the <= 64-row tiles) at the
+    // price of a second barrier per stage; the three register stages still keep two stages of global loads in flight
+    const int dbl = p.single_buf ? 0 : 1;
     auto step = [&](int st, auto CUR, auto NXT) {
         if (st >= ns) return;
         if (st + 3 < ns) load_stage(st + 3, CUR);
-        compute_stage(st & 1);
-        if (st + 1 < ns) store_stage((st + 1) & 1, NXT);
+        compute_stage((st & 1) & dbl);
+        if (!dbl) __syncthreads();
+        if (st + 1 < ns) store_stage(((st + 1) & 1) & dbl, NXT);
         __syncthreads();
     };
     if (ns > 0) load_stage(0, IC<0>{});
@@ -1237,12 +1242,13 @@ int dispatch_igemm(const IGemmP& p, hipStream_t s) {
 template <typename T, int BMG, int BNG, int WM, int WN, int SRC, bool ONE_TAP>
 int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
     constexpr int BR = WGTraits<T>::BR;
-    constexpr int lds = sizeof(T) == 2 ? 4 * BR * 288 : 2 * BR * (BMG * (int)sizeof(T) + 16) + 2 * BR * (BNG * (int)sizeof(T) + 16);
+    constexpr int lds2 = sizeof(T) == 2 ? 4 * BR * 288 : 2 * BR * (BMG * (int)sizeof(T) + 16) + 2 * BR * (BNG * (int)sizeof(T) + 16);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMG, BNG, WM, WN, SRC, ONE_TAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BMG, BNG, WM, WN, SRC, ONE_TAP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         attr_done = true;
     }
+    const int lds = p.single_buf ? lds2 / 2 : lds2;
     dim3 grid(sde_cdiv(p.Cout, BMG) * sde_cdiv(p.g.Ktot, BNG) * splits);
     hipLaunchKernelGGL((wgrad_kernel<T, BMG, BNG, WM, WN, SRC, ONE_TAP>), grid, dim3(NTHREADS), lds, s, p);
     return 0;
@@ -1412,6 +1418,8 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     rps = sde_cdiv(rps, BR) * BR;
     SDE_CHECK_ARG((long)rps * splits >= p.g.M, "sde_conv_wgrad: split arithmetic");
     p.dy = dy; p.slab = slab; p.Cout = Cout; p.ldd = ldd; p.rows_per_split = rps;
+    static const int sb = [] { const char* e = getenv("SDE_WGRAD_SINGLE_BUF"); return e ? atoi(e) : 0; }();
+    p.single_buf = (sb && d->dtype == SDE_BF16 && wgrad_bmg(Cout) <= 64) ? 1 : 0;
     if (d->dtype == SDE_BF16) dispatch_wgrad<bf16_t>(p, splits, s);
     else dispatch_wgrad<float>(p, splits, s);
     SDE_CHECK_LAUNCH("sde_conv_wgrad");
