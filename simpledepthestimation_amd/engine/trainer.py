@@ -149,6 +149,9 @@ class HipTrainer:
         finally:
             HN.WGRAD_DEFER = None
             if self._wreduce is not None:
+                if self._wreduce.forked:                                  # backward raised before the flush: still join the side stream
+                    torch.cuda.current_stream().wait_stream(HN.L.side_stream())
+                    self._wreduce.forked = False
                 self._wreduce.jobs, self._wreduce._seen = [], set()       # nothing left registered if backward raised
 
     def _backward_rest(self):

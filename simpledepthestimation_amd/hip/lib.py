@@ -112,6 +112,7 @@ def stream():
 
 _side = {}
 SIDE_STREAM = os.environ.get("SDE_WGRAD_SIDE_STREAM", "1") != "0"
+LATE_JOIN = os.environ.get("SDE_LATE_JOIN", "1") != "0"      # join the side stream once per backward phase (at the reducer's flush), not per layer
 
 
 def side_stream():

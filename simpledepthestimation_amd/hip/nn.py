@@ -245,6 +245,16 @@ class _Conv2d(torch.autograd.Function):
                                                                                  int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
                 if forked:
                     slab.record_stream(side)
+            # With a deferred reduction the join with the side stream can wait until the reducer's flush: the weight-gradient GEMMs then
+            # run freely behind the data-gradient chain instead of in lock-step with it.  Their operands must outlive this node:
+            # record_stream keeps the blocks from being recycled before the side stream has passed them.
+            late_join = forked and defer is not None and L.LATE_JOIN
+            if late_join:
+                for t in (dz, x0, x1):
+                    if t is not None:
+                        t.record_stream(side)
+                defer.forked = True
+                forked = False
             if wslot is not None:
                 dw = None
         # 3. data gradient
@@ -289,6 +299,7 @@ class WGradReducer:
 
     def __init__(self):
         self.jobs, self._seen = [], set()
+        self.forked = False        # some GEMM of this phase still runs on the side stream (late join)
 
     def accepts(self, wslot):
         # a weight used twice in one phase (shared modules) must not be accumulated by two blocks of one launch: the second use reduces at once
@@ -299,6 +310,9 @@ class WGradReducer:
         self.jobs.append((slab, wslot, (src_ptr, wslot.data_ptr(), rows, Cout, KHW, Cin_pad, Cin_real, 1)))
 
     def flush(self):
+        if self.forked:
+            torch.cuda.current_stream().wait_stream(L.side_stream())
+            self.forked = False
         if not self.jobs:
             return
         items = []
