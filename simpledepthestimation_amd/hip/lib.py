@@ -112,7 +112,10 @@ def stream():
 
 _side = {}
 SIDE_STREAM = os.environ.get("SDE_WGRAD_SIDE_STREAM", "1") != "0"
-LATE_JOIN = os.environ.get("SDE_LATE_JOIN", "1") != "0"      # join the side stream once per backward phase (at the reducer's flush), not per layer
+# SDE_LATE_JOIN=1 joins the side stream once per backward phase (at the reducer's flush) instead of after every layer.  Measured WORSE
+# (10.39 vs 9.69 ms/step, Supervised R50): operands kept alive for the lagging GEMMs stop the allocator from recycling hot blocks, and the
+# step's working set falls out of the 256 MB Infinity Cache.  Off by default; kept as an experiment knob.
+LATE_JOIN = os.environ.get("SDE_LATE_JOIN", "0") == "1"
 
 
 def side_stream():
