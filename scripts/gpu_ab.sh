@@ -5,9 +5,5 @@ run() { name=$1; shift
   echo "$WL $name $(python -c "import json;d=json.load(open('gpurun_out/ab.json'));print(d['value'], d['ms_per_step'])")"
 }
 WL=sup_r50 run warmup SDE_X=0
-WL=sup_r50 run deferred SDE_X=0
-WL=sup_r50 run immediate SDE_DEFER_WGRAD=0
-WL=sup_r50 run deferred SDE_X=0
-WL=sup_r50 run immediate SDE_DEFER_WGRAD=0
-WL=mono_r18 run deferred SDE_X=0
-WL=mono_r18 run immediate SDE_DEFER_WGRAD=0
+for mb in 8 2 0 32 100000 8; do WL=sup_r50 run mb$mb SDE_DEFER_MAX_MB=$mb; done
+for mb in 8 2 0 32 100000; do WL=mono_r18 run mb$mb SDE_DEFER_MAX_MB=$mb; done

@@ -233,7 +233,10 @@ class _Conv2d(torch.autograd.Function):
                 import contextlib
                 wctx = contextlib.nullcontext()
             dw = wslot if wslot is not None else torch.empty_like(weight)
-            defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and WGRAD_DEFER.accepts(wslot)) else None
+            # small slab stacks wait for the phase's one batched reduction; big ones (ResNet-50's 20-40 MB stacks add up to ~1 GB per step)
+            # are summed at once on the side stream while they are still in the Infinity Cache and their block can be recycled
+            slab_bytes = 4 * splits * Cout * KH * KW * (C0 + C1)
+            defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and slab_bytes <= L.DEFER_MAX_BYTES and WGRAD_DEFER.accepts(wslot)) else None
             slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
             with wctx:
                 if defer is not None:
