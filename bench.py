@@ -279,7 +279,7 @@ def main():
             hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype, args.workload)
             if hbm is not None:
                 out["roofline_photometric"] = hbm        # MonoDepth2 workloads: the HBM-bound warp+SSIM kernel next to the dominant GEMM
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
