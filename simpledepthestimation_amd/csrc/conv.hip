@@ -119,6 +119,7 @@ struct IGemmP {
     int Cout, ldy, act;
     int ksplit;           // > 1: the K loop is cut into ksplit ranges, each workgroup writes its raw fp32 tile to ws[split][M][ldy]
     float* ws;            //      and splitk_finish_kernel sums them in a fixed order and applies bias / activation / statistics
+    int no_kfull;         // experiment switch (SDE_NO_KFULL): disable the scalar-offset 1x1 loader
 };
 
 constexpr int KSTAGE_BYTES = 128;   // K bytes per row per pipeline stage (2 MFMA sub-blocks of 64 B)
@@ -145,6 +146,10 @@ constexpr unsigned kOOB = 0x80000000u;      // every tensor is < 2 GiB, so this 
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
+// voffset per lane + a wave-uniform scalar offset (the K position of the pipeline stage): no per-load VALU address arithmetic
+__device__ __forceinline__ uint4 buf_load16s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
@@ -246,12 +251,33 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
     unsigned rowoff = kOOB;        // SRC_1X1: byte offset of this thread's input pixel
     if (SRC == SRC_1X1 && an >= 0) rowoff = (unsigned)(((an * g.H0 + aih) * g.W0 + aiw) * g.C0) * (unsigned)sizeof(T);
 
+    // SRC_1X1 with K a whole number of stages (every real 1x1 layer: Cin % 64 == 0): the lane's byte offsets never change -- the K
+    // position of a stage is a scalar offset of the buffer load, so a stage's loads cost no VALU instruction at all.
+    const bool kfull = SRC == SRC_1X1 && (g.Ktot % BK) == 0 && !p.no_kfull;
+    unsigned voffA = kOOB, voffB[B_PASSES];
+    if (SRC == SRC_1X1) {
+        if (an >= 0) voffA = rowoff + (unsigned)(ac0 * V) * (unsigned)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int row = r0 + i * B_ROWS_PER_PASS, n = n0 + row;
+            voffB[i] = (row < BN && n < p.Cout) ? (unsigned)(n * g.Ktot + cc * V) * (unsigned)sizeof(T) : kOOB;
+        }
+    }
+
     // Three register stages in flight over two LDS buffers: the loop is bound by load latency, not by MFMA issue, so stage s+3
     // is requested while stage s is multiplied and stage s+1 is written to LDS (the compiler's counted vmcnt keeps s+2, s+3 flying).
     uint4 ra[3][CPT], rb[3][B_PASSES];
 
     auto load_stage = [&](int s, auto SET) {
         constexpr int st = decltype(SET)::value;
+        if (SRC == SRC_1X1 && kfull) {
+            const unsigned soff = (unsigned)(s_begin + s) * (unsigned)KSTAGE_BYTES;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) ra[st][c] = buf_load16s(rs0, voffA + 16u * c, soff);      // kOOB + 16c stays out of range
+#pragma unroll
+            for (int i = 0; i < B_PASSES; ++i) rb[st][i] = buf_load16s(rsw, voffB[i], soff);
+            return;
+        }
         if (SRC == SRC_1X1) {
             const int k = (s_begin + s) * BK + ac0 * V;
 #pragma unroll
@@ -1339,6 +1365,8 @@ static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const flo
     SDE_CHECK_ARG(act == SDE_ACT_NONE || act == SDE_ACT_ELU, "sde_conv_fwd: bad act %d", act);
     p.w = w_packed; p.bias = bias; p.y = y; p.stats = stats; p.Cout = Cout; p.ldy = ldy; p.act = act;
     p.ksplit = 1; p.ws = nullptr;
+    static const int no_kfull = [] { const char* e = getenv("SDE_NO_KFULL"); return e ? atoi(e) : 0; }();
+    p.no_kfull = no_kfull;
     const int S = ws ? pick_ksplit(p.g, d->dtype, ldy) : 1;
     if (S > 1) {
         SDE_CHECK_ARG(ws_bytes >= (size_t)S * p.g.M * ldy * sizeof(float), "sde_conv_fwd_ws: workspace too small (%zu bytes)", ws_bytes);
