@@ -254,14 +254,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
     // SRC_1X1 with K a whole number of stages (every real 1x1 layer: Cin % 64 == 0): the lane's byte offsets never change -- the K
     // position of a stage is a scalar offset of the buffer load, so a stage's loads cost no VALU instruction at all.
     const bool kfull = SRC == SRC_1X1 && (g.Ktot % BK) == 0 && !p.no_kfull;
+    const bool kfullB = (g.Ktot % BK) == 0 && !p.no_kfull;       // the same for the weight rows of every source kind
     unsigned voffA = kOOB, voffB[B_PASSES];
-    if (SRC == SRC_1X1) {
-        if (an >= 0) voffA = rowoff + (unsigned)(ac0 * V) * (unsigned)sizeof(T);
+    if (SRC == SRC_1X1 && an >= 0) voffA = rowoff + (unsigned)(ac0 * V) * (unsigned)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) {
-            const int row = r0 + i * B_ROWS_PER_PASS, n = n0 + row;
-            voffB[i] = (row < BN && n < p.Cout) ? (unsigned)(n * g.Ktot + cc * V) * (unsigned)sizeof(T) : kOOB;
-        }
+    for (int i = 0; i < B_PASSES; ++i) {
+        const int row = r0 + i * B_ROWS_PER_PASS, n = n0 + row;
+        voffB[i] = (row < BN && n < p.Cout) ? (unsigned)(n * g.Ktot + cc * V) * (unsigned)sizeof(T) : kOOB;
     }
 
     // Three register stages in flight over two LDS buffers: the loop is bound by load latency, not by MFMA issue, so stage s+3
@@ -314,6 +313,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) igemm_kernel(IGemmP p) {
         if (SRC != SRC_1X1) {       // advance the thread's base (tap, channel) position by one stage (BK elements)
             aci += BK;
             while (aci >= g.Cin) { aci -= g.Cin; if (++akw == g.KW) { akw = 0; ++akh; } }
+        }
+        if (kfullB) {
+            const unsigned soff = (unsigned)(s_begin + s) * (unsigned)KSTAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < B_PASSES; ++i) rb[st][i] = buf_load16s(rsw, voffB[i], soff);
+            return;
         }
         const int k = (s_begin + s) * BK + cc * V;
         const bool kok = k < g.Ktot;
