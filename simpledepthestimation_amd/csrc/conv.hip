@@ -1451,7 +1451,7 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     rps = sde_cdiv(rps, BR) * BR;
     SDE_CHECK_ARG((long)rps * splits >= p.g.M, "sde_conv_wgrad: split arithmetic");
     p.dy = dy; p.slab = slab; p.Cout = Cout; p.ldd = ldd; p.rows_per_split = rps;
-    static const int sb = [] { const char* e = getenv("SDE_WGRAD_SINGLE_BUF"); return e ? atoi(e) : 0; }();
+    static const int sb = [] { const char* e = getenv("SDE_WGRAD_SINGLE_BUF"); return e ? atoi(e) : 1; }();      // measured -0.7 % step time
     p.single_buf = (sb && d->dtype == SDE_BF16 && wgrad_bmg(Cout) <= 64) ? 1 : 0;
     if (d->dtype == SDE_BF16) dispatch_wgrad<bf16_t>(p, splits, s);
     else dispatch_wgrad<float>(p, splits, s);
