@@ -210,78 +210,102 @@ class _Conv2d(torch.autograd.Function):
                 dbias = None
             if dz is None:
                 dz = dy
-        # 2. weight gradient -- on the side stream when a data gradient follows, so the two independent GEMMs overlap
-        dw = None
+        st = {"dw": None, "forked": False, "side": None, "dx0": None, "dx1": None}
         need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
-        forked = False
-        if ctx.needs_input_grad[2]:
-            d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
-            splits = lib.sde_conv_wgrad_splits(ctypes.byref(d), Cout)
-            wslot = _grad_slot(ctx.params[0])
-            meta = None
-            if L.PROFILE is not None:
-                esz = 2 if dt == torch.bfloat16 else 4
-                meta = dict(M=M, N=Cout, K=KH * KW * (C0 + C1), k=KH, s=stride, mode=int(upcat), splits=splits,
-                            bytes=esz * (B * H0 * W0 * C0 + B * IH * IW * C1 + M * ldy) + 8 * splits * Cout * KH * KW * (C0 + C1))
-            forked = need_dx and L.SIDE_STREAM and L.PROFILE is None
-            cur = torch.cuda.current_stream()
-            if forked:
-                side = L.side_stream()
-                side.wait_stream(cur)
-                wctx = torch.cuda.stream(side)
-            else:
-                import contextlib
-                wctx = contextlib.nullcontext()
-            dw = wslot if wslot is not None else torch.empty_like(weight)
-            # small slab stacks wait for the phase's one batched reduction; big ones (ResNet-50's 20-40 MB stacks add up to ~1 GB per step)
-            # are summed at once on the side stream while they are still in the Infinity Cache and their block can be recycled
-            slab_bytes = 4 * splits * Cout * KH * KW * (C0 + C1)
-            defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and slab_bytes <= L.DEFER_MAX_BYTES and WGRAD_DEFER.accepts(wslot)) else None
-            slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
-            with wctx:
-                if defer is not None:
-                    _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits, L.stream()),
-                                                              "sde_conv_wgrad_partial"), meta)
-                    defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin)
-                else:
-                    _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
-                                                                                 int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
+        will_fork = bool(ctx.needs_input_grad[2]) and need_dx and L.SIDE_STREAM and L.PROFILE is None
+        # SDE_DGRAD_FIRST: enqueue the data-gradient GEMM before forking the weight-gradient one (same dependencies; only the order in
+        # which the two independent launches reach the queues / the captured graph differs)
+        fork_event = None
+        if will_fork and L.DGRAD_FIRST:
+            fork_event = torch.cuda.Event()
+            fork_event.record(torch.cuda.current_stream())
+
+        def do_wgrad():
+            # 2. weight gradient -- on the side stream when a data gradient follows, so the two independent GEMMs overlap
+            dw = None
+            forked = False
+            side = None
+            if ctx.needs_input_grad[2]:
+                d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
+                splits = lib.sde_conv_wgrad_splits(ctypes.byref(d), Cout)
+                wslot = _grad_slot(ctx.params[0])
+                meta = None
+                if L.PROFILE is not None:
+                    esz = 2 if dt == torch.bfloat16 else 4
+                    meta = dict(M=M, N=Cout, K=KH * KW * (C0 + C1), k=KH, s=stride, mode=int(upcat), splits=splits,
+                                bytes=esz * (B * H0 * W0 * C0 + B * IH * IW * C1 + M * ldy) + 8 * splits * Cout * KH * KW * (C0 + C1))
+                forked = need_dx and L.SIDE_STREAM and L.PROFILE is None
+                cur = torch.cuda.current_stream()
                 if forked:
-                    slab.record_stream(side)
-            # With a deferred reduction the join with the side stream can wait until the reducer's flush: the weight-gradient GEMMs then
-            # run freely behind the data-gradient chain instead of in lock-step with it.  Their operands must outlive this node:
-            # record_stream keeps the blocks from being recycled before the side stream has passed them.
-            late_join = forked and defer is not None and L.LATE_JOIN
-            if late_join:
-                for t in (dz, x0, x1):
-                    if t is not None:
-                        t.record_stream(side)
-                defer.forked = True
-                forked = False
-            if wslot is not None:
-                dw = None
-        # 3. data gradient
-        dx0 = dx1 = None
-        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            Cv = C0 + C1
-            wd = ctx.wd_pre if ctx.wd_pre is not None else pack_weight(weight, dt, Cv, ldy, for_dgrad=True)   # [Cv][KH][KW][ldy], taps flipped
-            if reflect:
-                dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1, False, OH, OW, IH + 2, IW + 2)
-                dxp, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
-                dx0 = torch.empty_like(x0)
-                dx1 = torch.empty_like(x1) if x1 is not None else None
-                L.check(lib.sde_refl_fold(L.ptr(dxp), B, IH, IW, Cv, C0, int(upcat), dtype_code(dt), L.ptr(dx0), L.ptr(dx1), L.stream()), "sde_refl_fold")
-            else:
-                if upcat:
-                    raise L.SdeHipError("upsample+concat source is only supported with reflection padding (decoder)")
-                if stride == 1:
-                    dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1 - pad, False, OH, OW, IH, IW)
-                elif stride == 2:
-                    # virtual zero-inserted gradient image: Z[2i, 2j] = dz[i, j]
-                    dd = _desc(dz, None, SRC_ZEROINS, KH, KW, 1, KH - 1 - pad, False, 2 * OH - 1, 2 * OW - 1, IH, IW)
+                    side = L.side_stream()
+                    if fork_event is not None:
+                        side.wait_event(fork_event)         # dz was ready when the event was recorded (before the data-gradient launch)
+                    else:
+                        side.wait_stream(cur)
+                    wctx = torch.cuda.stream(side)
                 else:
-                    raise L.SdeHipError(f"stride {stride} not supported")
-                dx0, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
+                    import contextlib
+                    wctx = contextlib.nullcontext()
+                dw = wslot if wslot is not None else torch.empty_like(weight)
+                # small slab stacks wait for the phase's one batched reduction; big ones (ResNet-50's 20-40 MB stacks add up to ~1 GB per step)
+                # are summed at once on the side stream while they are still in the Infinity Cache and their block can be recycled
+                slab_bytes = 4 * splits * Cout * KH * KW * (C0 + C1)
+                defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and slab_bytes <= L.DEFER_MAX_BYTES and WGRAD_DEFER.accepts(wslot)) else None
+                slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
+                with wctx:
+                    if defer is not None:
+                        _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits, L.stream()),
+                                                                  "sde_conv_wgrad_partial"), meta)
+                        defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin)
+                    else:
+                        _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
+                                                                                     int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
+                    if forked:
+                        slab.record_stream(side)
+                # With a deferred reduction the join with the side stream can wait until the reducer's flush: the weight-gradient GEMMs then
+                # run freely behind the data-gradient chain instead of in lock-step with it.  Their operands must outlive this node:
+                # record_stream keeps the blocks from being recycled before the side stream has passed them.
+                late_join = forked and defer is not None and L.LATE_JOIN
+                if late_join:
+                    for t in (dz, x0, x1):
+                        if t is not None:
+                            t.record_stream(side)
+                    defer.forked = True
+                    forked = False
+                if wslot is not None:
+                    dw = None
+            st["dw"], st["forked"], st["side"] = dw, forked, side
+
+        def do_dgrad():
+            # 3. data gradient
+            dx0 = dx1 = None
+            if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+                Cv = C0 + C1
+                wd = ctx.wd_pre if ctx.wd_pre is not None else pack_weight(weight, dt, Cv, ldy, for_dgrad=True)   # [Cv][KH][KW][ldy], taps flipped
+                if reflect:
+                    dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1, False, OH, OW, IH + 2, IW + 2)
+                    dxp, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
+                    dx0 = torch.empty_like(x0)
+                    dx1 = torch.empty_like(x1) if x1 is not None else None
+                    L.check(lib.sde_refl_fold(L.ptr(dxp), B, IH, IW, Cv, C0, int(upcat), dtype_code(dt), L.ptr(dx0), L.ptr(dx1), L.stream()), "sde_refl_fold")
+                else:
+                    if upcat:
+                        raise L.SdeHipError("upsample+concat source is only supported with reflection padding (decoder)")
+                    if stride == 1:
+                        dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1 - pad, False, OH, OW, IH, IW)
+                    elif stride == 2:
+                        # virtual zero-inserted gradient image: Z[2i, 2j] = dz[i, j]
+                        dd = _desc(dz, None, SRC_ZEROINS, KH, KW, 1, KH - 1 - pad, False, 2 * OH - 1, 2 * OW - 1, IH, IW)
+                    else:
+                        raise L.SdeHipError(f"stride {stride} not supported")
+                    dx0, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
+            st["dx0"], st["dx1"] = dx0, dx1
+
+        if fork_event is not None:
+            do_dgrad(); do_wgrad()
+        else:
+            do_wgrad(); do_dgrad()
+        dw, forked, side, dx0, dx1 = st["dw"], st["forked"], st["side"], st["dx0"], st["dx1"]
         if forked:
             torch.cuda.current_stream().wait_stream(side)       # join: dz / x0 / x1 stay alive until both GEMMs are done
         return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
