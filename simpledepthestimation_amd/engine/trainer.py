@@ -151,6 +151,7 @@ class HipTrainer:
         finally:
             HN.WGRAD_DEFER = None
             if self._wreduce is not None:
+                self._wreduce.join_pending()
                 if self._wreduce.forked:                                  # backward raised before the flush: still join the side stream
                     torch.cuda.current_stream().wait_stream(HN.L.side_stream())
                     self._wreduce.forked = False

@@ -116,7 +116,7 @@ SIDE_STREAM = os.environ.get("SDE_WGRAD_SIDE_STREAM", "1") != "0"
 # (10.39 vs 9.69 ms/step, Supervised R50): operands kept alive for the lagging GEMMs stop the allocator from recycling hot blocks, and the
 # step's working set falls out of the 256 MB Infinity Cache.  Off by default; kept as an experiment knob.
 LATE_JOIN = os.environ.get("SDE_LATE_JOIN", "0") == "1"
-DGRAD_FIRST = os.environ.get("SDE_DGRAD_FIRST", "0") == "1"        # launch order of the two independent backward GEMMs of a layer
+JOIN_LAG = os.environ.get("SDE_JOIN_LAG", "0") == "1"              # join a layer's weight-gradient GEMM one layer later (bounded lag, operands held)
 DEFER_MAX_BYTES = int(float(os.environ.get("SDE_DEFER_MAX_MB", "2")) * (1 << 20))     # weight-gradient slab stacks up to this size join the batched reduction
 
 

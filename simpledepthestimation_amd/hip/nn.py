@@ -212,14 +212,6 @@ class _Conv2d(torch.autograd.Function):
                 dz = dy
         st = {"dw": None, "forked": False, "side": None, "dx0": None, "dx1": None}
         need_dx = ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1])
-        will_fork = bool(ctx.needs_input_grad[2]) and need_dx and L.SIDE_STREAM and L.PROFILE is None
-        # SDE_DGRAD_FIRST: enqueue the data-gradient GEMM before forking the weight-gradient one (same dependencies; only the order in
-        # which the two independent launches reach the queues / the captured graph differs)
-        fork_event = None
-        if will_fork and L.DGRAD_FIRST:
-            fork_event = torch.cuda.Event()
-            fork_event.record(torch.cuda.current_stream())
-
         def do_wgrad():
             # 2. weight gradient -- on the side stream when a data gradient follows, so the two independent GEMMs overlap
             dw = None
@@ -238,10 +230,9 @@ class _Conv2d(torch.autograd.Function):
                 cur = torch.cuda.current_stream()
                 if forked:
                     side = L.side_stream()
-                    if fork_event is not None:
-                        side.wait_event(fork_event)         # dz was ready when the event was recorded (before the data-gradient launch)
-                    else:
-                        side.wait_stream(cur)
+                    if WGRAD_DEFER is not None:
+                        WGRAD_DEFER.join_pending()          # the previous layer's lagging join (no-op without SDE_JOIN_LAG)
+                    side.wait_stream(cur)
                     wctx = torch.cuda.stream(side)
                 else:
                     import contextlib
@@ -301,13 +292,16 @@ class _Conv2d(torch.autograd.Function):
                     dx0, _ = conv_raw(dd, dt, wd, None, ACT_NONE, Cv, Cv, False, dev, "igemm_dgrad", flops)
             st["dx0"], st["dx1"] = dx0, dx1
 
-        if fork_event is not None:
-            do_dgrad(); do_wgrad()
-        else:
-            do_wgrad(); do_dgrad()
+        do_wgrad()       # first: launching the data-gradient GEMM ahead of the fork measured 10 % slower end to end
+        do_dgrad()
         dw, forked, side, dx0, dx1 = st["dw"], st["forked"], st["side"], st["dx0"], st["dx1"]
         if forked:
-            torch.cuda.current_stream().wait_stream(side)       # join: dz / x0 / x1 stay alive until both GEMMs are done
+            if L.JOIN_LAG and WGRAD_DEFER is not None:
+                # lag-1 join: the main stream goes on with the next layer's backward and joins this layer's weight-gradient GEMM when the
+                # next convolution forks (or at the reducer's flush); the operands are kept alive until then
+                WGRAD_DEFER.pending_join = (side, (dz, x0, x1, weight))
+            else:
+                torch.cuda.current_stream().wait_stream(side)       # join: dz / x0 / x1 stay alive until both GEMMs are done
         return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
 
 
@@ -327,6 +321,12 @@ class WGradReducer:
     def __init__(self):
         self.jobs, self._seen = [], set()
         self.forked = False        # some GEMM of this phase still runs on the side stream (late join)
+        self.pending_join = None   # (side stream, operands) of the last convolution whose join is lagging by one layer (SDE_JOIN_LAG)
+
+    def join_pending(self):
+        if self.pending_join is not None:
+            torch.cuda.current_stream().wait_stream(self.pending_join[0])
+            self.pending_join = None
 
     def accepts(self, wslot):
         # a weight used twice in one phase (shared modules) must not be accumulated by two blocks of one launch: the second use reduces at once
@@ -337,6 +337,7 @@ class WGradReducer:
         self.jobs.append((slab, wslot, (src_ptr, wslot.data_ptr(), rows, Cout, KHW, Cin_pad, Cin_real, 1)))
 
     def flush(self):
+        self.join_pending()
         if self.forked:
             torch.cuda.current_stream().wait_stream(L.side_stream())
             self.forked = False
