@@ -231,7 +231,7 @@ class _Conv2d(torch.autograd.Function):
                 if forked:
                     side = L.side_stream()
                     if WGRAD_DEFER is not None:
-                        WGRAD_DEFER.join_pending()          # the previous layer's lagging join (no-op without SDE_JOIN_LAG)
+                        WGRAD_DEFER.join_pending(keep=L.JOIN_LAG - 1)      # lagging joins of earlier layers
                     side.wait_stream(cur)
                     wctx = torch.cuda.stream(side)
                 else:
@@ -296,10 +296,12 @@ class _Conv2d(torch.autograd.Function):
         do_dgrad()
         dw, forked, side, dx0, dx1 = st["dw"], st["forked"], st["side"], st["dx0"], st["dx1"]
         if forked:
-            if L.JOIN_LAG and WGRAD_DEFER is not None:
-                # lag-1 join: the main stream goes on with the next layer's backward and joins this layer's weight-gradient GEMM when the
-                # next convolution forks (or at the reducer's flush); the operands are kept alive until then
-                WGRAD_DEFER.pending_join = (side, (dz, x0, x1, weight))
+            if L.JOIN_LAG > 0 and WGRAD_DEFER is not None:
+                # lagging join: the main stream goes on with the next layers' backward and joins this layer's weight-gradient GEMM
+                # SDE_JOIN_LAG convolutions later (or at the reducer's flush); the operands are kept alive until then
+                ev = torch.cuda.Event()
+                ev.record(side)
+                WGRAD_DEFER.pending.append((ev, (dz, x0, x1)))
             else:
                 torch.cuda.current_stream().wait_stream(side)       # join: dz / x0 / x1 stay alive until both GEMMs are done
         return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
@@ -321,12 +323,13 @@ class WGradReducer:
     def __init__(self):
         self.jobs, self._seen = [], set()
         self.forked = False        # some GEMM of this phase still runs on the side stream (late join)
-        self.pending_join = None   # (side stream, operands) of the last convolution whose join is lagging by one layer (SDE_JOIN_LAG)
+        self.pending = []          # (event behind a layer's side-stream work, its operands) of convolutions whose join is lagging (SDE_JOIN_LAG)
 
-    def join_pending(self):
-        if self.pending_join is not None:
-            torch.cuda.current_stream().wait_stream(self.pending_join[0])
-            self.pending_join = None
+    def join_pending(self, keep=0):
+        """Make the current stream wait for all but the newest `keep` lagging weight-gradient GEMMs and release their operands."""
+        while len(self.pending) > max(0, keep):
+            ev, _refs = self.pending.pop(0)
+            torch.cuda.current_stream().wait_event(ev)
 
     def accepts(self, wslot):
         # a weight used twice in one phase (shared modules) must not be accumulated by two blocks of one launch: the second use reduces at once
