@@ -117,9 +117,9 @@ SIDE_STREAM = os.environ.get("SDE_WGRAD_SIDE_STREAM", "1") != "0"
 # step's working set falls out of the 256 MB Infinity Cache.  Off by default; kept as an experiment knob.
 LATE_JOIN = os.environ.get("SDE_LATE_JOIN", "0") == "1"
 # Join a layer's weight-gradient GEMM (side stream) this many convolutions later instead of at the end of its own backward: the main stream
-# runs on into the next layers' BatchNorm / data-gradient work instead of idling at the per-layer join (measured 9.06-9.22 vs 9.54 ms/step
-# with a lag of 1); operands of the lagging layers are held alive, so the working set grows by that many layers only.
-JOIN_LAG = int(os.environ.get("SDE_JOIN_LAG", "1"))
+# runs on into the next layers' BatchNorm / data-gradient work instead of idling at the per-layer join (measured, ms/step: lag 0 9.54,
+# 1 9.20, 2 9.01, 3 9.10, 5 9.21); operands of the lagging layers are held alive, so the working set grows by that many layers only.
+JOIN_LAG = int(os.environ.get("SDE_JOIN_LAG", "2"))
 DEFER_MAX_BYTES = int(float(os.environ.get("SDE_DEFER_MAX_MB", "2")) * (1 << 20))     # weight-gradient slab stacks up to this size join the batched reduction
 
 
