@@ -121,7 +121,7 @@ def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50"):
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     tot_ms = sum(f["ms"] for f in fam.values()); tot_fl = sum(f["flops"] for f in fam.values())
     if dom_key[0] != "igemm":
-        name = "wgrad_kernel(+slab_fold_kernel)"
+        name = "wgrad_kernel<bf16,64x128>" if dtype == "bf16" else "wgrad_kernel<f32>"
     elif dom_key[1] >= 3000000:
         name = f"halo3_kernel<{dtype},8x16 pixels x {dom_key[1] % 1000}>"
     else:

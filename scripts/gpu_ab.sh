@@ -1,13 +1,17 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -q -m gpu 2>&1 | tail -3 > gpurun_out/kf_tests.log; cat gpurun_out/kf_tests.log
+SDE_SIDE_STREAMS=2 timeout -k 10 900 python -m pytest tests/test_gpu_models.py -q -m gpu -x 2>&1 | tail -2 > gpurun_out/kf_tests.log; cat gpurun_out/kf_tests.log
 if grep -q "HSA_STATUS_ERROR\|Aborted\|dumped core\|Fatal Python error\|failed" gpurun_out/kf_tests.log; then echo "stop"; exit 3; fi
-SDE_JOIN_LAG=3 timeout -k 10 900 python -m pytest tests/test_gpu_models.py -q -m gpu -x 2>&1 | tail -2
 run() { name=$1; shift
   env "$@" timeout -k 10 200 python bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline --profile-steps 0 $EXTRA > gpurun_out/ab.json 2> gpurun_out/ab.err || { echo "failed $name"; tail -3 gpurun_out/ab.err; exit 1; }
   if grep -q "HSA_STATUS" gpurun_out/ab.err; then echo "fault $name"; exit 3; fi
   echo "$WL $name $(python -c "import json;d=json.load(open('gpurun_out/ab.json'));print(d['value'], d['ms_per_step'])")"
 }
 WL=sup_r50 run warmup SDE_X=0
-for lag in 1 2 3 5 0 1; do WL=sup_r50 run lag$lag SDE_JOIN_LAG=$lag; done
-for lag in 1 2 3; do WL=mono_r18 run lag$lag SDE_JOIN_LAG=$lag; done
-EXTRA=--force-overlap WL=sup_r50 run lag1_overlap SDE_X=0
+WL=sup_r50 run s1 SDE_X=0
+WL=sup_r50 run s2 SDE_SIDE_STREAMS=2
+WL=sup_r50 run s3 SDE_SIDE_STREAMS=3
+WL=sup_r50 run s2_lag3 SDE_SIDE_STREAMS=2 SDE_JOIN_LAG=3
+WL=sup_r50 run s2_lag4 SDE_SIDE_STREAMS=2 SDE_JOIN_LAG=4
+WL=sup_r50 run s1 SDE_X=0
+WL=mono_r18 run s1 SDE_X=0
+WL=mono_r18 run s2 SDE_SIDE_STREAMS=2

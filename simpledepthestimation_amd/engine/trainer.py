@@ -153,7 +153,8 @@ class HipTrainer:
             if self._wreduce is not None:
                 self._wreduce.join_pending()
                 if self._wreduce.forked:                                  # backward raised before the flush: still join the side stream
-                    torch.cuda.current_stream().wait_stream(HN.L.side_stream())
+                    for st_ in HN.L.all_side_streams():
+                        torch.cuda.current_stream().wait_stream(st_)
                     self._wreduce.forked = False
                 self._wreduce.jobs, self._wreduce._seen = [], set()       # nothing left registered if backward raised
 

@@ -123,13 +123,25 @@ JOIN_LAG = int(os.environ.get("SDE_JOIN_LAG", "2"))
 DEFER_MAX_BYTES = int(float(os.environ.get("SDE_DEFER_MAX_MB", "2")) * (1 << 20))     # weight-gradient slab stacks up to this size join the batched reduction
 
 
-def side_stream():
-    """Per-device helper stream: weight-gradient GEMMs run on it concurrently with the data-gradient GEMM of the same layer
-    (fork/join with stream waits, so it is captured into the step's hipGraph as a parallel branch)."""
+N_SIDE = max(1, int(os.environ.get("SDE_SIDE_STREAMS", "1")))      # weight-gradient GEMMs of consecutive layers alternate over this many streams
+_side_rr = [0]
+
+
+def side_stream(rotate=True):
+    """Per-device helper stream(s): weight-gradient GEMMs run there concurrently with the data-gradient GEMM of the same layer (fork/join
+    with stream / event waits, so they are captured into the step's hipGraph as parallel branches).  With SDE_SIDE_STREAMS > 1 consecutive
+    layers alternate over the streams, so two weight-gradient GEMMs can be in flight at once."""
     d = torch.cuda.current_device()
     if d not in _side:
-        _side[d] = torch.cuda.Stream(device=d)
-    return _side[d]
+        _side[d] = [torch.cuda.Stream(device=d) for _ in range(N_SIDE)]
+    if rotate:
+        _side_rr[0] = (_side_rr[0] + 1) % N_SIDE
+    return _side[d][_side_rr[0]]
+
+
+def all_side_streams():
+    d = torch.cuda.current_device()
+    return list(_side.get(d, []))
 
 
 def ptr_array(tensors):

@@ -342,7 +342,8 @@ class WGradReducer:
     def flush(self):
         self.join_pending()
         if self.forked:
-            torch.cuda.current_stream().wait_stream(L.side_stream())
+            for st_ in L.all_side_streams():
+                torch.cuda.current_stream().wait_stream(st_)
             self.forked = False
         if not self.jobs:
             return
