@@ -249,8 +249,15 @@ class _Conv2d(torch.autograd.Function):
                                                                   "sde_conv_wgrad_partial"), meta)
                         defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin)
                     else:
-                        _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw),
-                                                                                     int(wslot is not None), L.stream()), "sde_conv_wgrad"), meta)
+                        if L.PROFILE is None:
+                            L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw), int(wslot is not None), L.stream()),
+                                    "sde_conv_wgrad")
+                        else:       # the same two launches, timed separately (bench.py's roofline pass: GEMM FLOPs against GEMM time)
+                            _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits,
+                                                                                                 L.stream()), "sde_conv_wgrad_partial"), meta)
+                            one = (WReduceItem * 1)(WReduceItem(slab.data_ptr(), dw.data_ptr(), splits, Cout, KH * KW, C0 + C1, Cin, int(wslot is not None)))
+                            _timed("wgrad_reduce", 0.0, 0, lambda: L.check(lib.sde_wgrad_reduce_batched(one, 1, L.stream()), "sde_wgrad_reduce_batched"),
+                                   dict(jobs=1))
                     if forked:
                         slab.record_stream(side)
                 # With a deferred reduction the join with the side stream can wait until the reducer's flush: the weight-gradient GEMMs then
