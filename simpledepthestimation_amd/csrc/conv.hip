@@ -1287,7 +1287,7 @@ int launch_wgrad(const WGradP& p, int splits, hipStream_t s) {
 
 template <typename T, int BMG, int BNG, int WM, int WN>
 int dispatch_wsrc(const WGradP& p, int splits, hipStream_t s) {
-    constexpr int group = 4 * VecOf<T>::V;     // CPTB chunks of V elements
+    constexpr int group = BNG / (NTHREADS / WGTraits<T>::BR);     // elements covered by a thread's CPTB chunks
     if (sizeof(T) == 4 || (p.g.mode == SDE_SRC_UPCAT && !p.g.reflect) || p.g.mode == SDE_SRC_ZEROINS)
         return launch_wgrad<T, BMG, BNG, WM, WN, SRC_RUNTIME, false>(p, splits, s);
     const bool ot = one_tap_ok(p.g, group);
@@ -1299,6 +1299,10 @@ int dispatch_wsrc(const WGradP& p, int splits, hipStream_t s) {
     }
 }
 
+int wgrad_bng() {       // K-tile width of the weight-gradient GEMM for Cout >= 64 layers: 128, or 64 (experiment: SDE_WGRAD_BNG=64)
+    static const int v = [] { const char* e = getenv("SDE_WGRAD_BNG"); return (e && atoi(e) == 64) ? 64 : 128; }();
+    return v;
+}
 int wgrad_bmg(int Cout) {
     // 64 x 128 (Cout x K) tiles by default: twice the tiles of 128 x 128, so half the pixel splits / fp32 slabs for the same number of
     // workgroups (measured 10.03 vs 10.12 ms/step); SDE_WGRAD_BMG=128 restores the wide tile
@@ -1311,7 +1315,7 @@ template <typename T>
 int dispatch_wgrad(const WGradP& p, int splits, hipStream_t s) {
     switch (wgrad_bmg(p.Cout)) {
         case 128: return dispatch_wsrc<T, 128, 128, 2, 2>(p, splits, s);
-        case 64: return dispatch_wsrc<T, 64, 128, 1, 4>(p, splits, s);
+        case 64: return wgrad_bng() == 64 ? dispatch_wsrc<T, 64, 64, 2, 2>(p, splits, s) : dispatch_wsrc<T, 64, 128, 1, 4>(p, splits, s);
         case 32: return dispatch_wsrc<T, 32, 128, 1, 4>(p, splits, s);
         default: return dispatch_wsrc<T, 16, 128, 1, 4>(p, splits, s);
     }
@@ -1426,7 +1430,7 @@ int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
 int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     const long M = (long)d->Bn * d->OH * d->OW;
     const int Ktot = d->KH * d->KW * (d->C0 + d->C1);
-    const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, 128);
+    const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, wgrad_bmg(Cout) == 64 ? wgrad_bng() : 128);
     const int BR = d->dtype == SDE_BF16 ? 64 : 32;
     static const long target = [] { const char* e = getenv("SDE_WGRAD_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 256L; }();
     long want = (target + tiles - 1) / tiles;               // default 256 (one workgroup per CU): measured best end to end -- every extra split is another fp32 slab through HBM
