@@ -331,6 +331,44 @@ def test_weight_packer_equals_per_layer_pack(NN, dtype):
         assert torch.equal(wd, NN.pack_weight(m.weight, dt, cin_pad, ldy, for_dgrad=True)), f"dgrad operand {ci}->{co} k{k}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 6, 20, 256, 512, 3, True), (1, 12, 40, 2048, 256, 1, False), (2, 6, 20, 2048, 256, 3, False)],
+                         ids=["3x3_256_512_bias_elu", "1x1_2048_256_stats", "3x3_2048_256_stats"])
+def test_split_k_equals_single_pass(NN, dtype, shape):
+    """sde_conv_fwd_ws (split-K: partial tiles + fixed-order finish kernel) against sde_conv_fwd (one pass over K) on the same operands:
+    outputs, padded channels, and the BatchNorm partial slabs (summed over tiles)."""
+    import ctypes
+    from simpledepthestimation_amd.hip import lib as L
+    B, H, W, Cin, Cout, k, with_bias = shape
+    g = torch.Generator().manual_seed(Cin + Cout)
+    V = 4 if dtype == torch.float32 else 8
+    x = nhwc(torch.randn(B, Cin, H, W, generator=g), dtype, V)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).to(dev)
+    bias = (torch.randn(Cout, generator=g) * 0.1).to(dev) if with_bias else None
+    act = NN.ACT_ELU if with_bias else NN.ACT_NONE
+    ldy = (Cout + V - 1) // V * V
+    wp = NN.pack_weight(w, dtype, x.shape[-1], ldy)
+    d = NN._desc(x, None, NN.SRC_PLAIN, k, k, 1, k // 2, False, H, W, H, W)
+    lib = L.lib()
+    ws_bytes = lib.sde_conv_fwd_ws_bytes(ctypes.byref(d), ldy)
+    assert ws_bytes > 0, "shape was chosen to run split-K"
+    tiles = lib.sde_conv_fwd_tiles_m(ctypes.byref(d), ldy)
+    outs = []
+    for use_ws in (False, True):
+        y = torch.empty(B, H, W, ldy, device=dev, dtype=dtype)
+        stats = None if with_bias else torch.zeros(tiles + NN.REDUCE_ROWS, Cout, 2, device=dev)
+        ws = torch.empty(ws_bytes // 4, device=dev) if use_ws else None
+        if use_ws:
+            L.check(lib.sde_conv_fwd_ws(ctypes.byref(d), L.ptr(wp), L.ptr(bias), act, L.ptr(y), Cout, ldy, L.ptr(stats), L.ptr(ws), ws_bytes, L.stream()), "ws")
+        else:
+            L.check(lib.sde_conv_fwd(ctypes.byref(d), L.ptr(wp), L.ptr(bias), act, L.ptr(y), Cout, ldy, L.ptr(stats), L.stream()), "plain")
+        outs.append((y.float().cpu(), None if stats is None else stats[:tiles].sum(0).cpu()))
+    check(outs[1][0], outs[0][0], dtype, "split-K output", 2e-5, 1e-2)
+    assert (outs[1][0][..., Cout:] == 0).all()
+    if outs[0][1] is not None:
+        check(outs[1][1], outs[0][1], dtype, "split-K BN partial sums", 1e-4, 1e-2)
+
+
 def test_prep_input(NN):
     g = torch.Generator().manual_seed(3)
     img = torch.rand(2, 3, 10, 14, generator=g)
