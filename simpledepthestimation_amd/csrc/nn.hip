@@ -11,6 +11,7 @@
 // Layout: activations NHWC, 16-byte channel groups; every kernel moves 16 B per lane per access with lanes running along
 // the channel-fastest axis (full 1 KiB per wave instruction).  Channel reductions write per-workgroup partial slabs that a
 // small second kernel sums in fixed order (fp64) -- no float atomics, bit-reproducible statistics and gradients.
+#include <stdlib.h>
 #include "common.h"
 #include "sde_hip.h"
 
@@ -936,8 +937,9 @@ int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu
 
 int sde_reduce_num_blocks(long M, int C) {
     // ~4 sixteen-byte groups per thread (bf16 grouping), enough workgroups to keep HBM busy: these passes are pure streaming
+    static const long cap = [] { const char* e = getenv("SDE_REDUCE_MAX_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 2048L; }();
     long nb = (M * (long)C / 8 + 1023) / 1024;
-    if (nb > 2048) nb = 2048;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
