@@ -248,14 +248,37 @@ def gen_packnet(ref):
     print("packnet.npz", len(res), "arrays")
 
 
+def gen_options(ref):
+    """Config switches off in the reference's YAMLs but on its path: MODEL.DEPTH_NET.UPSAMPLE_DEPTH=True in training (DepthResNet.py:L62-63)."""
+    res = {}
+    sd = OM.init_state_dict(18, with_pose=True, seed=7)
+    cfg = ref_harness.make_cfg("MonoDepth2Model", "18")
+    cfg.MODEL.DEPTH_NET.UPSAMPLE_DEPTH = True
+    model = ref.MonoDepth2Fixed(cfg)
+    load_ref_weights(model, sd)
+    model.train()
+    batch = mono_batch(2, 64, 192, 21)
+    out = model({k: ([x.clone() for x in v] if isinstance(v, list) else v.clone()) for k, v in batch.items()})
+    (out["rec_loss"] + out["smooth_loss"]).backward()
+    res["mono18_up.rec_loss"] = np.float64(out["rec_loss"].item()); res["mono18_up.smooth_loss"] = np.float64(out["smooth_loss"].item())
+    for n, v in grad_norms(model, PROBE_PARAMS + ["pose_net.conv1.0.weight", "pose_net.pose_pred.weight"]).items():
+        res[f"mono18_up.gnorm.{n}"] = np.float64(v)
+    np.savez_compressed(os.path.join(OUT, "options.npz"), **res)
+    print("options.npz", len(res), "arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_harness.load()
+    if "--options-only" in sys.argv:
+        gen_options(ref)
+        return
     if "--packnet-only" not in sys.argv:
         gen_geometry(ref)
         gen_models(ref)
     gen_packnet(ref)
+    gen_options(ref)
 
 
 if __name__ == "__main__":

@@ -191,13 +191,14 @@ def monodepth2_losses(depths, poses, image, contexts, intrinsics, ssim_w=0.85, C
     return out
 
 
-def monodepth2_forward(sd, batch, num_layers, max_depth=80.0, training=True, update_running=False, **loss_kw):
+def monodepth2_forward(sd, batch, num_layers, max_depth=80.0, training=True, update_running=False, upsample_depth=False, **loss_kw):
     """MonoDepth2.py:L55-128.  num_layers: 18 / 34 / 50 (DepthResNet) or "packnet1A" / "packnet1B" (PackNet01)."""
     x = normalise(sd, batch["img"])
     if isinstance(num_layers, str) and num_layers.startswith("packnet"):
         depths = N.packnet01(sd, x, num_layers[-1], max_depth, bool(batch.get("flip", False)))
     else:
-        depths, _ = N.depth_resnet(sd, x, num_layers, max_depth, bool(batch.get("flip", False)), training, update_running)
+        depths, _ = N.depth_resnet(sd, x, num_layers, max_depth, bool(batch.get("flip", False)), training, update_running,
+                                   upsample_depth=upsample_depth)
     if not training:
         return {"depth_pred": depths[0]}
     pin = torch.cat([batch["img"]] + list(batch["ctx_img"]), 1)

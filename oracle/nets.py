@@ -130,7 +130,7 @@ def disp_to_depth(disp, min_depth, max_depth):
 
 
 def depth_resnet(sd, x, num_layers, max_depth=80.0, flip=False, training=True, update_running=False,
-                 prefix="depth_net."):
+                 prefix="depth_net.", upsample_depth=False):
     """DepthResNet.py:L45-70 -> list of 4 depth maps (index 0 = full resolution)."""
     if flip:
         x = torch.flip(x, [3])
@@ -139,6 +139,8 @@ def depth_resnet(sd, x, num_layers, max_depth=80.0, flip=False, training=True, u
     depths = [disp_to_depth(disps[i], 0.1, max_depth)[1] for i in range(4)]
     if flip:
         depths = [torch.flip(d, [3]) for d in depths]
+    if upsample_depth:       # DepthResNet.py:L62-63
+        depths = [F.interpolate(d, size=x.shape[-2:], mode="nearest") for d in depths]
     return depths, feats
 
 

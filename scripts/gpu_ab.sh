@@ -1,13 +1,2 @@
 mkdir -p gpurun_out
-run() { name=$1; shift
-  env "$@" timeout -k 10 200 python bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline --profile-steps 0 $EXTRA > gpurun_out/ab.json 2> gpurun_out/ab.err || { echo "failed $name"; tail -3 gpurun_out/ab.err; exit 1; }
-  if grep -q "HSA_STATUS" gpurun_out/ab.err; then echo "fault $name"; exit 3; fi
-  echo "$WL $name $(python -c "import json;d=json.load(open('gpurun_out/ab.json'));print(d['value'], d['ms_per_step'])")"
-}
-WL=sup_r50 run warmup SDE_X=0
-WL=sup_r50 run cap2048 SDE_X=0
-WL=sup_r50 run cap512 SDE_REDUCE_MAX_BLOCKS=512
-WL=sup_r50 run cap1024_pre1024 SDE_REDUCE_MAX_BLOCKS=1024 SDE_PRE_REDUCE_ROWS=1024
-WL=sup_r50 run cap768_pre768 SDE_REDUCE_MAX_BLOCKS=768 SDE_PRE_REDUCE_ROWS=768
-WL=sup_r50 run cap2048 SDE_X=0
-WL=sup_r50 run cap512 SDE_REDUCE_MAX_BLOCKS=512
+timeout -k 10 900 python -m pytest tests/test_gpu_models.py -q -m gpu 2>&1 | tail -6 > gpurun_out/kf_tests.log; cat gpurun_out/kf_tests.log

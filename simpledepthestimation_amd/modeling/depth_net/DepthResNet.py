@@ -1,6 +1,7 @@
 """DepthResNet = ResnetEncoder + DepthDecoder + disp_to_depth (reference: detectron2/modeling/depth_net/DepthResNet.py:L15-70)."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ...hip import nn as HN
 from ...hip import photometric as HP
@@ -48,9 +49,9 @@ class DepthResNet(nn.Module):
         logits = self.decoder(feats)
         disps = [HN.depth_head(logits[("disp_logit", i)], self.min_depth, self.max_depth, flip) for i in range(4)]
         if self.upsample_depth:
-            if torch.is_grad_enabled() and any(d.requires_grad for d in disps):
-                raise NotImplementedError("UPSAMPLE_DEPTH=True is supported for inference only (false in every reference config)")
-            size = x.shape[1:3]
-            disps = [HP.resize(d, size, mode="nearest") for d in disps]
+            # DepthResNet.py:L62-63: resize_img(d, input size, mode='nearest') -- a 1-channel nearest up-sampling whose backward is the sum over
+            # each replicated block: torch's own device op (F.interpolate), exactly what the reference calls
+            size = tuple(x.shape[1:3])
+            disps = [F.interpolate(d, size=size, mode="nearest") for d in disps]
         batch.update({"res2": disps[3], "res3": disps[2], "res4": disps[1], "depth_pred": disps})
         return batch

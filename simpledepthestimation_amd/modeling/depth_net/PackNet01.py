@@ -8,9 +8,9 @@ from functools import partial
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ...hip import nn as HN
-from ...hip import photometric as HP
 from ...layers.depth_decoder import disp_to_depth
 from ...layers.layers01 import Conv2D, InvDepth, PackLayerConv3d, ResidualBlock, UnpackLayerConv3d
 from .build import DEPTH_NET_REGISTRY
@@ -129,9 +129,7 @@ class PackNet01(nn.Module):
         disps = [self.scale_inv_depth(d.unsqueeze(1))[1] for d in (disp1, disp2, disp3, disp4)]
         if flip:
             disps = [torch.flip(d, [3]) for d in disps]
-        if self.upsample_depth:
-            if torch.is_grad_enabled() and any(d.requires_grad for d in disps):
-                raise NotImplementedError("UPSAMPLE_DEPTH=True is supported for inference only (false in every reference config)")
-            disps = [HP.resize(d.contiguous(), x.shape[1:3], mode="nearest") for d in disps]
+        if self.upsample_depth:       # PackNet01.py:L203-204
+            disps = [F.interpolate(d.contiguous(), size=tuple(x.shape[1:3]), mode="nearest") for d in disps]
         batch["depth_pred"] = disps
         return batch

@@ -43,3 +43,8 @@ def mod():
 @pytest.fixture(scope="session")
 def pack():
     return _Golden(os.path.join(GOLDEN, "packnet.npz"))
+
+
+@pytest.fixture(scope="session")
+def opt():
+    return _Golden(os.path.join(GOLDEN, "options.npz"))

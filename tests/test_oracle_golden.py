@@ -174,3 +174,15 @@ def test_packnet_model(pack, version):
         for i, d in enumerate(depths):
             close(d, pack.t(f"{tag}.depth{i}"), 1e-4, 1e-6)
         close(N.packnet01({k: v.detach() for k, v in sd.items()}, x, version, flip=True)[0], pack.t(f"{tag}.flip_depth0"), 1e-4, 1e-6)
+
+
+def test_monodepth2_upsample_depth(opt):
+    """MODEL.DEPTH_NET.UPSAMPLE_DEPTH=True in training (all four scales at the input resolution, DepthResNet.py:L62-63)."""
+    sd = _leaf(OM.init_state_dict(18, with_pose=True, seed=7))
+    out = OM.monodepth2_forward(sd, mono_batch(2, 64, 192, 21), 18, upsample_depth=True)
+    close(out["rec_loss"], opt["mono18_up.rec_loss"], 2e-5)
+    close(out["smooth_loss"], opt["mono18_up.smooth_loss"], 2e-4)
+    names = [k[len("mono18_up.gnorm."):] for k in opt.keys() if k.startswith("mono18_up.gnorm.")]
+    gn = _grad_norms(sd, out["rec_loss"] + out["smooth_loss"], names)
+    for n in names:
+        close(gn[n], opt[f"mono18_up.gnorm.{n}"], 5e-3, 1e-8)
