@@ -71,6 +71,8 @@ typedef struct sde_photo_desc {
     int32_t reduce_mean;           /* LOSS.PHOTOMETRIC_REDUCE: 0 = 'min', 1 = 'mean' */
     float sx, sy;                  /* scale_intrinsics factors w/W, h/H */
     float ssim_w, C1, C2;          /* LOSS.SSIM_WEIGHT, LOSS.C1, LOSS.C2 */
+    const float* clip_thr;         /* LOSS.CLIP > 0: device [nmaps] thresholds mean + clip*std of each UNCLIPPED map (MonoDepth2.py:L147-149:
+                                      one forward with maps != NULL and clip_thr == NULL yields them); NULL = no clipping */
 } sde_photo_desc;
 
 /* number of workgroups (= length of `partial`, and of pose_partial / (nctx*12) for backward) */

@@ -263,6 +263,17 @@ def gen_options(ref):
     res["mono18_up.rec_loss"] = np.float64(out["rec_loss"].item()); res["mono18_up.smooth_loss"] = np.float64(out["smooth_loss"].item())
     for n, v in grad_norms(model, PROBE_PARAMS + ["pose_net.conv1.0.weight", "pose_net.pose_pred.weight"]).items():
         res[f"mono18_up.gnorm.{n}"] = np.float64(v)
+    # LOSS.CLIP > 0 (MonoDepth2.py:L147-149), with both reductions
+    for red in ("min", "mean"):
+        tag = f"mono18_clip_{red}"
+        model = ref.MonoDepth2Fixed(ref_harness.make_cfg("MonoDepth2Model", "18", CLIP=0.5, PHOTOMETRIC_REDUCE=red))
+        load_ref_weights(model, sd)
+        model.train()
+        out = model({k: ([x.clone() for x in v] if isinstance(v, list) else v.clone()) for k, v in batch.items()})
+        (out["rec_loss"] + out["smooth_loss"]).backward()
+        res[f"{tag}.rec_loss"] = np.float64(out["rec_loss"].item()); res[f"{tag}.smooth_loss"] = np.float64(out["smooth_loss"].item())
+        for n, v in grad_norms(model, PROBE_PARAMS + ["pose_net.conv1.0.weight", "pose_net.pose_pred.weight"]).items():
+            res[f"{tag}.gnorm.{n}"] = np.float64(v)
     np.savez_compressed(os.path.join(OUT, "options.npz"), **res)
     print("options.npz", len(res), "arrays")
 

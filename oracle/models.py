@@ -153,7 +153,7 @@ def supervised_forward(sd, batch, num_layers, max_depth=80.0, variance_focus=0.8
 
 
 def monodepth2_losses(depths, poses, image, contexts, intrinsics, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True,
-                      smooth_w=1e-3, reduce="min", var_w=0.0):
+                      smooth_w=1e-3, reduce="min", var_w=0.0, clip=0.0):
     """MonoDepth2.py:L67-124 given the network outputs.
 
     depths: 4 x [B,1,h,w]; poses: list of [B,4,4]; image/contexts: original frames.
@@ -172,9 +172,9 @@ def monodepth2_losses(depths, poses, image, contexts, intrinsics, ssim_w=0.85, C
         for ctx, pose in zip(contexts, poses):
             ctx_i = G.resize_img(ctx, hw)
             maps.append(L.rgb_consistency(img_i, ctx_i, d, K_i, pose[:, :3, :3], pose[:, :3, 3],
-                                          ssim_w=ssim_w, C1=C1, C2=C2))
+                                          ssim_w=ssim_w, C1=C1, C2=C2, clip=clip))
             if automask:
-                maps.append(L.rgb_consistency(img_i, ctx_i, d, K_i, None, None, ssim_w=ssim_w, C1=C1, C2=C2))
+                maps.append(L.rgb_consistency(img_i, ctx_i, d, K_i, None, None, ssim_w=ssim_w, C1=C1, C2=C2, clip=clip))
         if reduce == "min":
             photo.append(L.min_reprojection(maps))
         else:

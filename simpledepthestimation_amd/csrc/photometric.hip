@@ -201,6 +201,7 @@ struct PhotoArgs {
     uint8_t* sel;
     float* partial;
     float* maps;   // optional [B, nmaps, h, w] per-map photometric values (tests / debugging), may be null
+    const float* thr;   // optional [nmaps] LOSS.CLIP thresholds (mean + clip * std of each unclipped map), may be null
     int B, h, w, nctx, automask, reduce_mean;
     float sx, sy, ssim_w, C1, C2;
 };
@@ -301,6 +302,7 @@ __global__ void __launch_bounds__(FT_N) photo_fwd_kernel(PhotoArgs a) {
         }
         float best = 0.f, acc = 0.f;
         int bi = 0;
+        unsigned clipped = 0;
 #pragma unroll
         for (int m = 0; m < 2 * NCTX; ++m) {
             const bool ident = m & 1;
@@ -309,12 +311,14 @@ __global__ void __launch_bounds__(FT_N) photo_fwd_kernel(PhotoArgs a) {
             float pm = l;
             if (a.ssim_w > 0.f) pm = (ss[m] / 3.0f) * a.ssim_w + l * (1.0f - a.ssim_w);
             const int mi = a.automask ? m : (m >> 1);
+            if (a.thr && pm > a.thr[mi]) { pm = a.thr[mi]; clipped |= 1u << mi; }      // torch.clamp(max=...): no gradient where it bites
             if (a.maps) a.maps[(((long)b * nmaps + mi) * h + gy) * w + gx] = pm;
             acc += pm;
             if (mi == 0 || pm < best) { best = pm; bi = mi; }
         }
         v = a.reduce_mean ? acc / (float)nmaps : best;
-        if (a.sel) a.sel[b * hw + (long)gy * w + gx] = a.reduce_mean ? 255 : (uint8_t)bi;
+        // sel: 'min' -> index of the arg-min map (254: it was clipped, no gradient); 'mean' -> bit mask of the clipped maps (255 without clipping)
+        if (a.sel) a.sel[b * hw + (long)gy * w + gx] = a.reduce_mean ? (a.thr ? (uint8_t)clipped : 255) : (((clipped >> bi) & 1u) ? 254 : (uint8_t)bi);
     }
     const float s = sde_block_sum(v, red);
     if (lp == 0) a.partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
@@ -334,7 +338,7 @@ struct PhotoBwdArgs {
     const float* gout;      // device scalar: upstream gradient of this scale's reduced loss
     float* d_depth;         // [B,1,h,w]
     float* pose_partial;    // [nblocks][NCTX][12]  (dR row-major 9, dt 3)
-    int B, h, w, nctx, automask, reduce_mean, accumulate;
+    int B, h, w, nctx, automask, reduce_mean, accumulate, clip;   // clip: sel carries LOSS.CLIP information (see photo_fwd_kernel)
     float sx, sy, ssim_w, C1, C2, gscale;   // gscale = 1/(B*h*w)  (mean over pixels)
 };
 
@@ -370,7 +374,8 @@ __global__ void __launch_bounds__(FT_N) photo_bwd_kernel(PhotoBwdArgs a) {
         __syncthreads();
         const int mi = a.automask ? 2 * j : j;
         // weight of this map's value at window centre (min: indicator of the arg-min; mean: 1/nmaps)
-        const float gw = win ? (a.reduce_mean ? g / (float)nmaps : (mysel == mi ? g : 0.f)) : 0.f;
+        const bool mean_on = !(a.clip && ((mysel >> mi) & 1));       // 'mean' reduce: this map's value was not clipped at this pixel
+        const float gw = win ? (a.reduce_mean ? (mean_on ? g / (float)nmaps : 0.f) : (mysel == mi ? g : 0.f)) : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float cA = 0.f, cB = 0.f, cC = 0.f;
@@ -408,7 +413,7 @@ __global__ void __launch_bounds__(FT_N) photo_bwd_kernel(PhotoBwdArgs a) {
         make_cam(a.K + 9 * b, a.pose[j] + 16 * b, a.sx, a.sy, cam);
         if (interior) {
             float ds[3];
-            const float l1w = a.reduce_mean ? g / (float)nmaps : (mysel == mi ? g : 0.f);
+            const float l1w = a.reduce_mean ? (mean_on ? g / (float)nmaps : 0.f) : (mysel == mi ? g : 0.f);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float xq = sX[c * FT_N + lp], aq = sA[c * FT_N + lp];
@@ -802,7 +807,7 @@ int sde_photo_fwd(const sde_photo_desc* d, float* const* sampled, uint8_t* sel, 
     SDE_CHECK_ARG(d->nctx >= 1 && d->nctx <= SDE_MAX_CTX, "sde_photo_fwd: nctx=%d out of range", d->nctx);
     SDE_CHECK_ARG(d->B > 0 && d->h >= 4 && d->w >= 4, "sde_photo_fwd: bad shape B=%d h=%d w=%d", d->B, d->h, d->w);
     PhotoArgs a;
-    a.A = d->A; a.depth = d->depth; a.K = d->K; a.sel = sel; a.partial = partial; a.maps = maps;
+    a.A = d->A; a.depth = d->depth; a.K = d->K; a.sel = sel; a.partial = partial; a.maps = maps; a.thr = d->clip_thr;
     for (int j = 0; j < SDE_MAX_CTX; ++j) {
         a.ctx[j] = j < d->nctx ? d->ctx[j] : nullptr;
         a.pose[j] = j < d->nctx ? d->pose[j] : nullptr;
@@ -843,7 +848,7 @@ int sde_photo_bwd(const sde_photo_desc* d, const float* const* sampled, const ui
         SDE_CHECK_ARG(j >= d->nctx || (a.ctx[j] && a.pose[j] && a.sampled[j] && d_pose[j]), "sde_photo_bwd: null ctx/pose/sampled %d", j);
     }
     a.B = d->B; a.h = d->h; a.w = d->w; a.nctx = d->nctx; a.automask = d->automask; a.reduce_mean = d->reduce_mean;
-    a.accumulate = accumulate_depth;
+    a.accumulate = accumulate_depth; a.clip = d->clip_thr != nullptr;
     a.sx = d->sx; a.sy = d->sy; a.ssim_w = d->ssim_w; a.C1 = d->C1; a.C2 = d->C2;
     a.gscale = gscale / ((float)d->B * d->h * d->w);
     dim3 grid(sde_cdiv(d->w, FT_W - 4), sde_cdiv(d->h, FT_H - 4), d->B), blk(FT_W, FT_H);

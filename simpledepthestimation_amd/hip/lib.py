@@ -21,7 +21,7 @@ class SdeHipError(RuntimeError):
 class PhotoDesc(Structure):
     _fields_ = [("A", c_void_p), ("ctx", c_void_p * MAX_CTX), ("pose", c_void_p * MAX_CTX), ("depth", c_void_p), ("K", c_void_p),
                 ("B", c_int32), ("h", c_int32), ("w", c_int32), ("nctx", c_int32), ("automask", c_int32), ("reduce_mean", c_int32),
-                ("sx", c_float), ("sy", c_float), ("ssim_w", c_float), ("C1", c_float), ("C2", c_float)]
+                ("sx", c_float), ("sy", c_float), ("ssim_w", c_float), ("C1", c_float), ("C2", c_float), ("clip_thr", c_void_p)]
 
 
 _P, _I, _F = c_void_p, c_int, c_float

@@ -67,8 +67,9 @@ def pose_vec2mat(vec):
     return _PoseVec2Mat.apply(vec)
 
 
-def _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean):
+def _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean, clip_thr=None):
     d = L.PhotoDesc()
+    d.clip_thr = clip_thr.data_ptr() if clip_thr is not None else 0
     B, _, h, w = depth.shape
     d.A = A.data_ptr(); d.depth = depth.data_ptr(); d.K = K.data_ptr()
     for j, (c, p) in enumerate(zip(ctxs, poses)):
@@ -83,7 +84,7 @@ class _PhotoScale(torch.autograd.Function):
     """One scale of MonoDepth2's photometric loss (MonoDepth2.py:L78-101,L116-124): returns mean(reduced map)."""
 
     @staticmethod
-    def forward(ctx, depth, K, A, sx, sy, ssim_w, C1, C2, automask, reduce_mean, nctx, *rest):
+    def forward(ctx, depth, K, A, sx, sy, ssim_w, C1, C2, automask, reduce_mean, clip, nctx, *rest):
         ctxs, poses = rest[:nctx], rest[nctx:]
         depth, K, A = _f32c(depth), _f32c(K), _f32c(A)
         ctxs = [_f32c(c) for c in ctxs]
@@ -91,7 +92,13 @@ class _PhotoScale(torch.autograd.Function):
         B, _, h, w = depth.shape
         dev = depth.device
         lib = L.lib()
-        d = _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean)
+        thr = None
+        if clip > 0.0:
+            # LOSS.CLIP (MonoDepth2.py:L147-149): every map is clamped at mean + clip * std of ITSELF; one extra forward yields the unclipped
+            # maps, the per-map statistics stay on the device (the reference converts them to a python float: same fp32 value, no gradient)
+            maps = photometric_maps(depth, K, A, ctxs, poses, sx, sy, ssim_w, C1, C2, automask, "mean" if reduce_mean else "min")["maps"]
+            thr = (maps.mean((0, 2, 3)) + clip * maps.std((0, 2, 3))).contiguous()
+        d = _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean, thr)
         sampled = [torch.empty(B, 3, h, w, device=dev) for _ in range(nctx)]
         sel = torch.empty(B, h, w, device=dev, dtype=torch.uint8)
         partial = torch.empty(lib.sde_photo_num_blocks(B, h, w, 0), device=dev)
@@ -102,6 +109,7 @@ class _PhotoScale(torch.autograd.Function):
                                 "sde_photo_fwd"), dict(B=B, h=h, w=w, moved=B * h * w * (16 + 24 * nctx + 1)))
         ctx.save_for_backward(depth, K, A, sel, *ctxs, *poses, *sampled)
         ctx.cfg = (sx, sy, ssim_w, C1, C2, automask, reduce_mean, nctx)
+        ctx.thr = thr
         return loss
 
     @staticmethod
@@ -113,7 +121,7 @@ class _PhotoScale(torch.autograd.Function):
         B, _, h, w = depth.shape
         dev = depth.device
         lib = L.lib()
-        d = _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean)
+        d = _desc(A, ctxs, poses, depth, K, sx, sy, ssim_w, C1, C2, automask, reduce_mean, ctx.thr)
         d_depth = torch.empty_like(depth)
         d_pose = [torch.empty(B, 4, 4, device=dev) for _ in range(nctx)]
         pp = torch.empty(lib.sde_photo_num_blocks(B, h, w, 1) * nctx * 12, device=dev)
@@ -122,14 +130,14 @@ class _PhotoScale(torch.autograd.Function):
         L.timed("photo_bwd", B * h * w * (21 + 24 * nctx), nctx,
                 lambda: L.check(lib.sde_photo_bwd(ctypes.byref(d), L.ptr_array(sampled), L.ptr(sel), L.ptr(gout), 1.0, L.ptr(d_depth), 0, L.ptr(pp),
                                                   L.ptr_array(d_pose), 0, L.stream()), "sde_photo_bwd"), dict(B=B, h=h, w=w))
-        return (d_depth, None, None, None, None, None, None, None, None, None, None) + (None,) * nctx + tuple(d_pose)
+        return (d_depth, None, None, None, None, None, None, None, None, None, None, None) + (None,) * nctx + tuple(d_pose)
 
 
-def photometric_scale_loss(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):
+def photometric_scale_loss(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min", clip=0.0):
     if reduce not in ("min", "mean"):
         raise NotImplementedError(reduce)           # MonoDepth2.py:L121-122
     return _PhotoScale.apply(depth, K, A, float(sx), float(sy), float(ssim_w), float(C1), float(C2), bool(automask), reduce == "mean",
-                             len(ctxs), *ctxs, *poses)
+                             float(clip), len(ctxs), *ctxs, *poses)
 
 
 def photometric_maps(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):

@@ -32,8 +32,6 @@ class MonoDepth2Model(nn.Module):
         self.sup_loss_w = cfg.LOSS.SUPERVISED_WEIGHT
         self.smooth_loss_w = cfg.LOSS.SMOOTHNESS_WEIGHT
         self.supervise_loss = silog_loss(cfg.LOSS.VARIANCE_FOCUS)
-        if self.clip_loss > 0.0:
-            raise NotImplementedError("LOSS.CLIP > 0 (mean + k*std clipping, MonoDepth2.py:L147-149) is 0.0 in every reference config")
         self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(1, -1, 1, 1))
         self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(1, -1, 1, 1))
 
@@ -65,7 +63,7 @@ class MonoDepth2Model(nn.Module):
             resized_targets = [HP.resize(c, (h, w)) for c in contexts]
             photo_losses.append(HP.photometric_scale_loss(depth_pred[i], intrinsics, resized_image, resized_targets, poses, w / W, h / H,
                                                           ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2,
-                                                          automask=self.use_automask, reduce=self.photometric_reduce))
+                                                          automask=self.use_automask, reduce=self.photometric_reduce, clip=self.clip_loss))
             if self.smooth_loss_w > 0.0:
                 losses["smooth_loss"] += smoothness_loss(depth_pred[i], resized_image) * (scale_w * self.smooth_loss_w / num_scales)
             if self.sup_loss_w > 0.0:

@@ -186,3 +186,16 @@ def test_monodepth2_upsample_depth(opt):
     gn = _grad_norms(sd, out["rec_loss"] + out["smooth_loss"], names)
     for n in names:
         close(gn[n], opt[f"mono18_up.gnorm.{n}"], 5e-3, 1e-8)
+
+
+@pytest.mark.parametrize("red", ["min", "mean"])
+def test_monodepth2_loss_clip(opt, red):
+    """LOSS.CLIP = 0.5: every photometric map clamped at mean + 0.5 std of itself (MonoDepth2.py:L147-149), 'min' and 'mean' reductions."""
+    tag = f"mono18_clip_{red}"
+    sd = _leaf(OM.init_state_dict(18, with_pose=True, seed=7))
+    out = OM.monodepth2_forward(sd, mono_batch(2, 64, 192, 21), 18, clip=0.5, reduce=red)
+    close(out["rec_loss"], opt[f"{tag}.rec_loss"], 2e-5)
+    names = [k[len(tag) + 7:] for k in opt.keys() if k.startswith(f"{tag}.gnorm.")]
+    gn = _grad_norms(sd, out["rec_loss"] + out["smooth_loss"], names)
+    for n in names:
+        close(gn[n], opt[f"{tag}.gnorm.{n}"], 5e-3, 1e-8)
