@@ -208,6 +208,7 @@ struct PhotoArgs {
 
 // clamp((1 - SSIM)/2, 0, 1) from the nine-tap sums (ssim_loss.py:L34-53: mu = avgpool3x3, sigma = E[x^2] - mu^2)
 __device__ __forceinline__ float ssim_from_moments(float sx, float sy, float sxx, float syy, float sxy, float C1, float C2) {
+#pragma clang fp contract(fast)
     const float inv9 = 1.0f / 9.0f;
     const float mx = sx * inv9, my = sy * inv9;
     const float mxy = mx * my, mxx = mx * mx, myy = my * my;
@@ -262,6 +263,9 @@ __global__ void __launch_bounds__(FT_N) photo_fwd_kernel(PhotoArgs a) {
     float v = 0.f;
     const bool interior = tx >= 1 && tx < FT_W - 1 && ty >= 1 && ty < FT_H - 1 && inimg;
     if (interior) {
+        // FMA contraction is fine here (and only here): the file is built with -ffp-contract=off for the projection chain, whose sample
+        // indices must match the reference bit for bit; the SSIM / L1 arithmetic is held to 1e-5 like every other fp32 map
+#pragma clang fp contract(fast)
         const int nmaps = a.automask ? 2 * NCTX : NCTX;
         // channel-outer / map-inner: the 3x3 moments of the target frame (sum y, sum y^2) and its nine values are shared by all
         // maps of a channel; every individual sum keeps the operand order of ssim_dist(), so the results are unchanged bit for bit
@@ -380,6 +384,7 @@ __global__ void __launch_bounds__(FT_N) photo_bwd_kernel(PhotoBwdArgs a) {
         for (int c = 0; c < 3; ++c) {
             float cA = 0.f, cB = 0.f, cC = 0.f;
             if (gw != 0.f && a.ssim_w > 0.f) {
+#pragma clang fp contract(fast)
                 const float* xs = sX + c * FT_N; const float* ys = sA + c * FT_N;
                 float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
 #pragma unroll
