@@ -371,6 +371,10 @@ __global__ void __launch_bounds__(FT_N) photo_bwd_kernel(PhotoBwdArgs a) {
     const float d = usable ? a.depth[b * hw + pix] : 1.f;
     float dd = 0.f;   // d loss / d depth at this pixel
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    __shared__ Cam scam[NCTX];       // camera matrices per (sample, context): built by one thread each, read back as LDS broadcasts
+#pragma unroll
+    for (int j = 0; j < NCTX; ++j)
+        if (lp == j) make_cam(a.K + 9 * b, a.pose[j] + 16 * b, a.sx, a.sy, scam[j]);
     for (int j = 0; j < NCTX; ++j) {
         __syncthreads();   // previous iteration's readers are done with sX / sK
 #pragma unroll
@@ -414,8 +418,7 @@ __global__ void __launch_bounds__(FT_N) photo_bwd_kernel(PhotoBwdArgs a) {
         float acc12[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) acc12[i] = 0.f;
-        Cam cam;
-        make_cam(a.K + 9 * b, a.pose[j] + 16 * b, a.sx, a.sy, cam);
+        const Cam cam = scam[j];
         if (interior) {
             float ds[3];
             const float l1w = a.reduce_mean ? (mean_on ? g / (float)nmaps : 0.f) : (mysel == mi ? g : 0.f);
