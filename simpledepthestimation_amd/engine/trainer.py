@@ -133,6 +133,8 @@ class HipTrainer:
         out = self.model(batch)
         loss_dict = {k: v for k, v in out.items() if "loss" in k}
         losses = sum(loss_dict.values())
+        if self._packer is not None:
+            self._packer.join_dgrad()
         self._backward(lambda: losses.backward())
         if self._packer is None and self.batch_pack:
             try:

@@ -120,6 +120,7 @@ LATE_JOIN = os.environ.get("SDE_LATE_JOIN", "0") == "1"
 # runs on into the next layers' BatchNorm / data-gradient work instead of idling at the per-layer join (measured, ms/step: lag 0 9.54,
 # 1 9.20, 2 9.01, 3 9.10, 5 9.21); operands of the lagging layers are held alive, so the working set grows by that many layers only.
 JOIN_LAG = int(os.environ.get("SDE_JOIN_LAG", "2"))
+PACK_SPLIT = os.environ.get("SDE_PACK_SPLIT", "0") == "1"          # pack the data-gradient operands on the side stream during the forward pass
 DEFER_MAX_BYTES = int(float(os.environ.get("SDE_DEFER_MAX_MB", "2")) * (1 << 20))     # weight-gradient slab stacks up to this size join the batched reduction
 
 

@@ -408,16 +408,39 @@ class WeightPacker:
             end += nb
             items.append((w.data_ptr(), wp.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, cin_pad, ldy, end))
             self._keep.append((w, wp, wd))
-        arr = (PackItem * len(items))(*[PackItem(*it) for it in items])
-        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-        self.items = torch.from_numpy(raw).to(convs[0].weight.device)
+        dev = convs[0].weight.device
+
+        def table(rows):
+            arr = (PackItem * len(rows))(*[PackItem(*it) for it in rows])
+            return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+        self.items = table(items)
+        # SDE_PACK_SPLIT: the data-gradient operands are not needed before backward -> pack them on the side stream, behind the forward
+        # operands and concurrently with the forward pass (join_dgrad() before backward)
+        self.items_fwd = table([it[:2] + (0,) + it[3:] for it in items])
+        self.items_dgrad = table([it[:1] + (0,) + it[2:] for it in items])
         self.n, self.total = len(items), end
         self._ptrs = [w.data_ptr() for w, _, _ in self._keep]
+        self._forked = False
 
     def run(self):
         if any(w.data_ptr() != p for (w, _, _), p in zip(self._keep, self._ptrs)):
             raise L.SdeHipError("WeightPacker: a weight tensor moved (e.g. flattened after the packer was built); rebuild the packer")
-        L.check(L.lib().sde_pack_weights_batched(L.ptr(self.items), self.n, self.total, dtype_code(self.dtype), L.stream()), "sde_pack_weights_batched")
+        lib, dc = L.lib(), dtype_code(self.dtype)
+        if not (L.PACK_SPLIT and L.SIDE_STREAM):
+            L.check(lib.sde_pack_weights_batched(L.ptr(self.items), self.n, self.total, dc, L.stream()), "sde_pack_weights_batched")
+            return
+        L.check(lib.sde_pack_weights_batched(L.ptr(self.items_fwd), self.n, self.total, dc, L.stream()), "sde_pack_weights_batched")
+        cur, side = torch.cuda.current_stream(), L.side_stream(rotate=False)
+        side.wait_stream(cur)                 # after the optimizer step that produced the weights (and after the forward-operand pack)
+        with torch.cuda.stream(side):
+            L.check(lib.sde_pack_weights_batched(L.ptr(self.items_dgrad), self.n, self.total, dc, L.stream()), "sde_pack_weights_batched")
+        self._forked = True
+
+    def join_dgrad(self):
+        """Call before backward: the data-gradient operands packed on the side stream must be complete."""
+        if self._forked:
+            torch.cuda.current_stream().wait_stream(L.side_stream(rotate=False))
+            self._forked = False
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, skip=None, upsample=False, bn_stats=False, owner=None):
