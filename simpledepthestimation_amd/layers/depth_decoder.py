@@ -1,33 +1,31 @@
-"""MonoDepth2-style depth decoder on the HIP convolution engine.
+"""MonoDepth2-style depth decoder on the HIP convolution engine (contract: detectron2/layers/depth_decoder.py:L9-110).
 
-Reference: detectron2/layers/depth_decoder.py:L9-110.  ModuleList order (= state-dict indices) is the reference's:
-upconv(4,0),(4,1),(3,0),...,(0,1), dispconv 0..3; ConvBlock parameters live at ``decoder.K.conv.conv.{weight,bias}``,
-dispconv at ``decoder.K.conv.{weight,bias}``.  Reflection padding, the nearest x2 upsample and the skip concat are folded into
-the convolution's loader; ELU into its epilogue.
+State-dict layout is the reference's: one ``decoder`` ModuleList holding, in this order, the two ELU convolutions of every level from the
+coarsest (4) to the finest (0), then the four disparity heads; ELU convolutions keep their parameters at ``decoder.K.conv.conv.*`` and
+heads at ``decoder.K.conv.*``.  What the reference does as separate modules -- reflection padding, the nearest x2 up-sampling, the skip
+concatenation, the ELU -- is folded into the convolution's loader / epilogue here, so a level is two kernel launches.
 """
-from collections import OrderedDict
-
-import numpy as np
-import torch.nn as nn
+from torch import nn
 
 from ..hip import nn as HN
 from .hip_modules import HipConv2d
 
+DEC_WIDTH = (16, 32, 64, 128, 256)        # decoder width per level, finest first
+
 
 def disp_to_depth(disp, min_depth, max_depth):
-    """depth_decoder.py:L9-18 (torch tensors; the training path uses the fused sde_depth_head_* kernels instead)."""
-    min_disp = 1 / max_depth
-    max_disp = 1 / min_depth
-    scaled_disp = min_disp + (max_disp - min_disp) * disp
-    depth = 1 / scaled_disp
-    return scaled_disp, depth
+    """Sigmoid disparity -> (scaled disparity, depth) between the two depth bounds (depth_decoder.py:L9-18).  Torch tensors; the training
+    path uses the fused ``sde_depth_head_*`` kernels instead."""
+    lo, hi = 1.0 / max_depth, 1.0 / min_depth
+    scaled = lo + (hi - lo) * disp
+    return scaled, 1.0 / scaled
 
 
 class Conv3x3(nn.Module):
-    """ReflectionPad2d(1) + Conv2d(3x3) (depth_decoder.py:L36-53)."""
+    """3x3 convolution over a reflection- (or zero-) padded input (depth_decoder.py:L36-53)."""
 
     def __init__(self, in_channels, out_channels, use_refl=True):
-        super().__init__()
+        nn.Module.__init__(self)
         self.conv = HipConv2d(int(in_channels), int(out_channels), 3, 1, 1, bias=True, reflect=use_refl)
 
     def forward(self, x, skip=None, upsample=False, act=HN.ACT_NONE):
@@ -35,10 +33,10 @@ class Conv3x3(nn.Module):
 
 
 class ConvBlock(nn.Module):
-    """Conv3x3 + ELU (depth_decoder.py:L21-33)."""
+    """Conv3x3 followed by ELU (depth_decoder.py:L21-33); the activation runs in the convolution's epilogue."""
 
     def __init__(self, in_channels, out_channels):
-        super().__init__()
+        nn.Module.__init__(self)
         self.conv = Conv3x3(in_channels, out_channels)
 
     def forward(self, x, skip=None, upsample=False):
@@ -47,30 +45,39 @@ class ConvBlock(nn.Module):
 
 class DepthDecoder(nn.Module):
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
-        super().__init__()
-        self.num_output_channels, self.use_skips, self.scales = num_output_channels, use_skips, scales
+        nn.Module.__init__(self)
         self.num_ch_enc = num_ch_enc
-        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
-        self.convs = OrderedDict()
-        for i in range(4, -1, -1):
-            num_ch_in = self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
-            self.convs[("upconv", i, 0)] = ConvBlock(num_ch_in, self.num_ch_dec[i])
-            num_ch_in = self.num_ch_dec[i]
-            if self.use_skips and i > 0:
-                num_ch_in += self.num_ch_enc[i - 1]
-            self.convs[("upconv", i, 1)] = ConvBlock(num_ch_in, self.num_ch_dec[i])
-        for s in self.scales:
-            self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
-        self.decoder = nn.ModuleList(list(self.convs.values()))
+        self.scales = scales
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        top = len(DEC_WIDTH) - 1
+        blocks, self._slot = [], {}
+        below = int(num_ch_enc[-1])
+        for lvl in range(top, -1, -1):
+            width = DEC_WIDTH[lvl]
+            skip_w = int(num_ch_enc[lvl - 1]) if (use_skips and lvl > 0) else 0
+            self._slot["reduce", lvl] = len(blocks)
+            blocks.append(ConvBlock(below, width))
+            self._slot["merge", lvl] = len(blocks)
+            blocks.append(ConvBlock(width + skip_w, width))
+            below = width
+        for s in scales:
+            self._slot["head", s] = len(blocks)
+            blocks.append(Conv3x3(DEC_WIDTH[s], num_output_channels))
+        self.decoder = nn.ModuleList(blocks)
+
+    def _block(self, kind, lvl):
+        return self.decoder[self._slot[kind, lvl]]
 
     def forward(self, input_features):
-        """Returns {("disp_logit", i): NHWC tensor whose channel 0 is the pre-softplus disparity} for the 4 scales."""
-        self.outputs = {}
-        x = input_features[-1]
-        for i in range(4, -1, -1):
-            x = self.convs[("upconv", i, 0)](x)
-            skip = input_features[i - 1] if (self.use_skips and i > 0) else None
-            x = self.convs[("upconv", i, 1)](x, skip=skip, upsample=True)     # upsample + cat happen in the loader
-            if i in self.scales:
-                self.outputs[("disp_logit", i)] = self.convs[("dispconv", i)](x)
-        return self.outputs
+        """Returns {("disp_logit", i): NHWC tensor whose channel 0 is the pre-activation disparity} for every scale."""
+        outputs = {}
+        feat = input_features[-1]
+        for lvl in range(len(DEC_WIDTH) - 1, -1, -1):
+            feat = self._block("reduce", lvl)(feat)
+            skip = input_features[lvl - 1] if (self.use_skips and lvl > 0) else None
+            feat = self._block("merge", lvl)(feat, skip=skip, upsample=True)        # up-sampling + concatenation happen in the loader
+            if lvl in self.scales:
+                outputs["disp_logit", lvl] = self._block("head", lvl)(feat)
+        self.outputs = outputs
+        return outputs

@@ -1,11 +1,14 @@
-"""`.module` shim for single-GPU runs (reference: detectron2/layers/fakeDDP.py:L4-10)."""
-import torch.nn as nn
+"""Single-process stand-in for DistributedDataParallel: gives the reference's training scripts the ``model.module`` attribute they reach
+through (``model.module.depth_net.encoder`` ...) when no process group exists.  Same contract as detectron2/layers/fakeDDP.py:L4-10."""
+from torch import nn
 
 
 class FakeDDP(nn.Module):
-    def __init__(self, model):
-        super().__init__()
-        self.module = model
+    """Wraps `wrapped` under the attribute name DDP uses; calls, ``train()``/``eval()`` and ``state_dict`` prefixes behave like DDP's."""
 
-    def forward(self, x):
-        return self.module(x)
+    def __init__(self, wrapped: nn.Module):
+        nn.Module.__init__(self)
+        self.add_module("module", wrapped)
+
+    def forward(self, *batch, **kw):
+        return self._modules["module"](*batch, **kw)

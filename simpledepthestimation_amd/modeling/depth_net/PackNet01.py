@@ -1,135 +1,113 @@
-"""PackNet01 (reference: detectron2/modeling/depth_net/PackNet01.py:L18-209; layers in layers/layers01.py) on the HIP kernels.
+"""PackNet01 on the HIP kernels.  Contract: detectron2/modeling/depth_net/PackNet01.py:L18-209 (its layers: layers/layers01.py).
 
-Same constructor contract (``cfg.MODEL.DEPTH_NET.VERSION`` = "1A" concatenation / "1B" addition), same module tree and state-dict
-keys, same batch contract: consumes ``depth_net_input`` (or the fused NHWC form), adds ``depth_pred`` = 4 x [B,1,h,w] fp32 metric depth,
-``disp_to_depth`` applied on top of sigmoid/0.5 as the reference does (PackNet01.py:L199).
+``cfg.MODEL.DEPTH_NET.VERSION`` selects "1A" (skips concatenated) or "1B" (skips added, half-width upper decoder).  Module names -- and so
+the state-dict keys -- are the reference's (``pre_calc``, ``conv1..5``, ``pack1..5``, ``unpack5..1``, ``iconv5..1``, ``dispN_layer``);
+they are created from the width tables below instead of being spelled out one by one.  Batch contract: reads ``depth_net_input`` (or the
+already laid-out ``depth_net_input_nhwc``), writes ``depth_pred`` = four [B,1,h,w] fp32 metric depth maps, finest first, obtained as
+``disp_to_depth(sigmoid(.)/0.5)`` exactly like L199; ``UPSAMPLE_DEPTH`` brings all of them to the input resolution (L203-204).
 """
-from functools import partial
-
 import torch
-import torch.nn as nn
 import torch.nn.functional as F
+from torch import nn
 
 from ...hip import nn as HN
+from ...layers import layers01 as L01
 from ...layers.depth_decoder import disp_to_depth
-from ...layers.layers01 import Conv2D, InvDepth, PackLayerConv3d, ResidualBlock, UnpackLayerConv3d
 from .build import DEPTH_NET_REGISTRY
 from .DepthResNet import compute_dtype
+
+WIDTH = {0: 64, 1: 64, 2: 64, 3: 128, 4: 256, 5: 512}        # level 0 = pre_calc output, levels 1..5 = encoder stages
+RES_BLOCKS = {2: 2, 3: 2, 4: 3, 5: 3}                        # residual blocks of conv2..conv5
+PACK_KERNEL = {1: 5, 2: 3, 3: 3, 4: 3, 5: 3}
+DISP_LEVELS = (1, 2, 3, 4)                                   # levels that emit an inverse-depth map
+MIN_DEPTH = 0.1
+
+
+def _decoder_widths(version):
+    """Per level: (unpack output width, iconv input width).  Levels 1..3 also take the up-sampled disparity of the level below them."""
+    table = {}
+    for lvl in range(1, 6):
+        w, skip_w = WIDTH[lvl], WIDTH[lvl - 1]
+        extra = 1 if lvl <= 3 else 0
+        if version == "A":
+            table[lvl] = (w, w + skip_w + extra)
+        else:
+            half = w // 2 if lvl >= 3 else w
+            table[lvl] = (half, half + extra)
+    return table
 
 
 def _cat(parts, vec):
     """Channel concatenation of NHWC tensors, zero-padded to the next multiple of the 16-byte group."""
-    c = sum(p.shape[-1] for p in parts)
-    pad = (-c) % vec
-    if pad:
-        B, H, W, _ = parts[0].shape
-        parts = list(parts) + [torch.zeros(B, H, W, pad, device=parts[0].device, dtype=parts[0].dtype)]
+    used = sum(p.shape[-1] for p in parts)
+    fill = (-used) % vec
+    if fill:
+        parts = [*parts, parts[0].new_zeros(*parts[0].shape[:3], fill)]
     return torch.cat(parts, -1)
 
 
 def _up2(disp):
-    """nn.Upsample(scale_factor=2, mode='nearest') of a [B,H,W] map -> [B,2H,2W]."""
+    """Nearest x2 of a [B,H,W] map (the reference's parameter-free ``unpack_disp*`` modules)."""
     return disp.repeat_interleave(2, 1).repeat_interleave(2, 2)
 
 
 @DEPTH_NET_REGISTRY.register()
 class PackNet01(nn.Module):
     def __init__(self, cfg, **kwargs):
-        super().__init__()
+        nn.Module.__init__(self)
         self.version = cfg.MODEL.DEPTH_NET.VERSION[1:]
-        in_channels, out_channels = 3, 1
-        ni, no = 64, out_channels
-        n1, n2, n3, n4, n5 = 64, 64, 128, 256, 512
-        num_blocks = [2, 2, 3, 3]
-        pack_kernel = [5, 3, 3, 3, 3]
-        unpack_kernel = [3, 3, 3, 3, 3]
-        iconv_kernel = [3, 3, 3, 3, 3]
-        self.pre_calc = Conv2D(in_channels, ni, 5, 1)
-        if self.version == "A":        # channel concatenation
-            n1o, n1i = n1, n1 + ni + no
-            n2o, n2i = n2, n2 + n1 + no
-            n3o, n3i = n3, n3 + n2 + no
-            n4o, n4i = n4, n4 + n3
-            n5o, n5i = n5, n5 + n4
-        elif self.version == "B":      # channel addition
-            n1o, n1i = n1, n1 + no
-            n2o, n2i = n2, n2 + no
-            n3o, n3i = n3 // 2, n3 // 2 + no
-            n4o, n4i = n4 // 2, n4 // 2
-            n5o, n5i = n5 // 2, n5 // 2
-        else:
+        if self.version not in ("A", "B"):
             raise ValueError("Unknown MonoDepth2 version {}".format(self.version))
-        # encoder
-        self.pack1 = PackLayerConv3d(n1, pack_kernel[0])
-        self.pack2 = PackLayerConv3d(n2, pack_kernel[1])
-        self.pack3 = PackLayerConv3d(n3, pack_kernel[2])
-        self.pack4 = PackLayerConv3d(n4, pack_kernel[3])
-        self.pack5 = PackLayerConv3d(n5, pack_kernel[4])
-        self.conv1 = Conv2D(ni, n1, 7, 1)
-        self.conv2 = ResidualBlock(n1, n2, num_blocks[0], 1, dropout=0.0)
-        self.conv3 = ResidualBlock(n2, n3, num_blocks[1], 1, dropout=0.0)
-        self.conv4 = ResidualBlock(n3, n4, num_blocks[2], 1, dropout=0.0)
-        self.conv5 = ResidualBlock(n4, n5, num_blocks[3], 1, dropout=0.0)
-        # decoder
-        self.unpack5 = UnpackLayerConv3d(n5, n5o, unpack_kernel[0])
-        self.unpack4 = UnpackLayerConv3d(n5, n4o, unpack_kernel[1])
-        self.unpack3 = UnpackLayerConv3d(n4, n3o, unpack_kernel[2])
-        self.unpack2 = UnpackLayerConv3d(n3, n2o, unpack_kernel[3])
-        self.unpack1 = UnpackLayerConv3d(n2, n1o, unpack_kernel[4])
-        self.iconv5 = Conv2D(n5i, n5, iconv_kernel[0], 1)
-        self.iconv4 = Conv2D(n4i, n4, iconv_kernel[1], 1)
-        self.iconv3 = Conv2D(n3i, n3, iconv_kernel[2], 1)
-        self.iconv2 = Conv2D(n2i, n2, iconv_kernel[3], 1)
-        self.iconv1 = Conv2D(n1i, n1, iconv_kernel[4], 1)
-        # depth layers (the reference's parameter-free unpack_disp* upsamplers are _up2 here)
-        self.disp4_layer = InvDepth(n4, out_channels=out_channels)
-        self.disp3_layer = InvDepth(n3, out_channels=out_channels)
-        self.disp2_layer = InvDepth(n2, out_channels=out_channels)
-        self.disp1_layer = InvDepth(n1, out_channels=out_channels)
-        self.scale_inv_depth = partial(disp_to_depth, min_depth=0.1, max_depth=cfg.MODEL.MAX_DEPTH)
+        self.pre_calc = L01.Conv2D(3, WIDTH[0], 5, 1)
+        self.conv1 = L01.Conv2D(WIDTH[0], WIDTH[1], 7, 1)
+        for lvl, blocks in RES_BLOCKS.items():
+            setattr(self, f"conv{lvl}", L01.ResidualBlock(WIDTH[lvl - 1], WIDTH[lvl], blocks, 1, dropout=0.0))
+        for lvl, k in PACK_KERNEL.items():
+            setattr(self, f"pack{lvl}", L01.PackLayerConv3d(WIDTH[lvl], k))
+        for lvl, (up_w, iconv_in) in _decoder_widths(self.version).items():
+            below = WIDTH[min(lvl + 1, 5)]                       # what feeds the unpack: iconv of the level below (pack5 at the bottom)
+            setattr(self, f"unpack{lvl}", L01.UnpackLayerConv3d(below, up_w, 3))
+            setattr(self, f"iconv{lvl}", L01.Conv2D(iconv_in, WIDTH[lvl], 3, 1))
+        for lvl in DISP_LEVELS:
+            setattr(self, f"disp{lvl}_layer", L01.InvDepth(WIDTH[lvl], out_channels=1))
+        self.max_depth = cfg.MODEL.MAX_DEPTH
         self.upsample_depth = cfg.MODEL.DEPTH_NET.UPSAMPLE_DEPTH
         self.dtype = compute_dtype(cfg)
         # no _grad_cut attribute: HipTrainer then all-reduces after the full backward (no two-phase overlap for this net)
 
-    def _join(self, unpack, skip, udisp=None):
-        vec = 8 if self.dtype == torch.bfloat16 else 4
-        parts = [unpack, skip] if self.version == "A" else [unpack + skip]
-        if udisp is not None:
-            parts.append(udisp.unsqueeze(-1).to(self.dtype))
-        return parts[0] if len(parts) == 1 else _cat(parts, vec)
+    def scale_inv_depth(self, disp):
+        return disp_to_depth(disp, min_depth=MIN_DEPTH, max_depth=self.max_depth)
+
+    def _join(self, unpacked, skip, disp_below=None):
+        parts = [unpacked, skip] if self.version == "A" else [unpacked + skip]
+        if disp_below is not None:
+            parts.append(_up2(disp_below).unsqueeze(-1).to(self.dtype))
+        if len(parts) == 1:
+            return parts[0]
+        return _cat(parts, 8 if self.dtype == torch.bfloat16 else 4)
 
     def forward(self, batch):
         flip = bool(batch.get("flip", False))
-        x = batch.get("depth_net_input_nhwc")
-        if x is None:
-            x = HN.prep_input(batch["depth_net_input"], None, None, self.dtype, flip)       # flip folded into the layout change
-        x = self.pre_calc(x)
-        # encoder
-        x1 = self.conv1(x)
-        x1p = self.pack1(x1)
-        x2 = self.conv2(x1p)
-        x2p = self.pack2(x2)
-        x3 = self.conv3(x2p)
-        x3p = self.pack3(x3)
-        x4 = self.conv4(x3p)
-        x4p = self.pack4(x4)
-        x5 = self.conv5(x4p)
-        x5p = self.pack5(x5)
-        skip1, skip2, skip3, skip4, skip5 = x, x1p, x2p, x3p, x4p
-        # decoder
-        iconv5 = self.iconv5(self._join(self.unpack5(x5p), skip5))
-        iconv4 = self.iconv4(self._join(self.unpack4(iconv5), skip4))
-        disp4 = self.disp4_layer(iconv4)
-        iconv3 = self.iconv3(self._join(self.unpack3(iconv4), skip3, _up2(disp4)))
-        disp3 = self.disp3_layer(iconv3)
-        iconv2 = self.iconv2(self._join(self.unpack2(iconv3), skip2, _up2(disp3)))
-        disp2 = self.disp2_layer(iconv2)
-        iconv1 = self.iconv1(self._join(self.unpack1(iconv2), skip1, _up2(disp2)))
-        disp1 = self.disp1_layer(iconv1)
-        disps = [self.scale_inv_depth(d.unsqueeze(1))[1] for d in (disp1, disp2, disp3, disp4)]
+        stem = batch.get("depth_net_input_nhwc")
+        if stem is None:
+            stem = HN.prep_input(batch["depth_net_input"], None, None, self.dtype, flip)       # flip folded into the layout change
+        stem = self.pre_calc(stem)
+        # encoder: packed[l] is the output of level l after its space-to-depth packing; packed[0] is the full-resolution stem
+        packed = {0: stem}
+        for lvl in range(1, 6):
+            feat = getattr(self, f"conv{lvl}")(packed[lvl - 1])
+            packed[lvl] = getattr(self, f"pack{lvl}")(feat)
+        # decoder, coarse to fine; the inverse depth of level l+1 is an extra input channel of levels 3..1
+        feat, disp = packed[5], {}
+        for lvl in range(5, 0, -1):
+            joined = self._join(getattr(self, f"unpack{lvl}")(feat), packed[lvl - 1], disp.get(lvl + 1))
+            feat = getattr(self, f"iconv{lvl}")(joined)
+            if lvl in DISP_LEVELS:
+                disp[lvl] = getattr(self, f"disp{lvl}_layer")(feat)
+        depth = [self.scale_inv_depth(disp[lvl].unsqueeze(1))[1] for lvl in DISP_LEVELS]
         if flip:
-            disps = [torch.flip(d, [3]) for d in disps]
-        if self.upsample_depth:       # PackNet01.py:L203-204
-            disps = [F.interpolate(d.contiguous(), size=tuple(x.shape[1:3]), mode="nearest") for d in disps]
-        batch["depth_pred"] = disps
+            depth = [d.flip(3) for d in depth]
+        if self.upsample_depth:
+            depth = [F.interpolate(d.contiguous(), size=tuple(stem.shape[1:3]), mode="nearest") for d in depth]
+        batch["depth_pred"] = depth
         return batch

@@ -4,47 +4,30 @@ is one fused kernel per scale; the image pyramid is built once per batch instead
 from collections import defaultdict
 
 import torch
-import torch.nn as nn
 
-from ...hip import nn as HN
 from ...hip import photometric as HP
-from ...utils.memory import to_cuda
-from ..depth_net import build_depth_net
 from ..losses.losses import silog_loss, variance_loss
 from ..losses.smoothness_loss import smoothness_loss
 from ..losses.ssim_loss import SSIM
 from ..pose_net import build_pose_net
 from .build import META_ARCH_REGISTRY
+from .common import HipMetaArch
 
 
 @META_ARCH_REGISTRY.register()
-class MonoDepth2Model(nn.Module):
+class MonoDepth2Model(HipMetaArch):
     def __init__(self, cfg):
-        super().__init__()
-        self.depth_net = build_depth_net(cfg)
+        HipMetaArch.__init__(self, cfg)
         self.pose_net = build_pose_net(cfg)
-        self.ssim = SSIM(cfg.LOSS.C1, cfg.LOSS.C2)
-        self.ssim_loss_weight = cfg.LOSS.SSIM_WEIGHT
-        self.photometric_reduce = cfg.LOSS.PHOTOMETRIC_REDUCE
-        self.use_automask = cfg.LOSS.AUTOMASK
-        self.clip_loss = cfg.LOSS.CLIP
-        self.var_loss_w = cfg.LOSS.VAR_LOSS_WEIGHT
-        self.sup_loss_w = cfg.LOSS.SUPERVISED_WEIGHT
-        self.smooth_loss_w = cfg.LOSS.SMOOTHNESS_WEIGHT
-        self.supervise_loss = silog_loss(cfg.LOSS.VARIANCE_FOCUS)
-        self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(1, -1, 1, 1))
-        self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(1, -1, 1, 1))
-
-    @property
-    def device(self):
-        return self.pixel_mean.device
+        loss = cfg.LOSS
+        self.ssim = SSIM(loss.C1, loss.C2)
+        self.ssim_loss_weight, self.photometric_reduce, self.use_automask, self.clip_loss = loss.SSIM_WEIGHT, loss.PHOTOMETRIC_REDUCE, loss.AUTOMASK, loss.CLIP
+        self.var_loss_w, self.sup_loss_w, self.smooth_loss_w = loss.VAR_LOSS_WEIGHT, loss.SUPERVISED_WEIGHT, loss.SMOOTHNESS_WEIGHT
+        self.supervise_loss = silog_loss(loss.VARIANCE_FOCUS)
 
     def forward(self, batch):
-        batch = to_cuda(batch, self.device)
+        batch = self.run_depth_net(batch)
         output = {}
-        batch["depth_net_input_nhwc"] = HN.prep_input(batch["img"], self.pixel_mean, self.pixel_std, self.depth_net.dtype,
-                                                      bool(batch.get("flip", False)))
-        batch = self.depth_net(batch)
         if not self.training:
             output["depth_pred"] = batch["depth_pred"][0]
             return output
