@@ -46,6 +46,12 @@ _C.SOLVER.CHECKPOINT_PERIOD = 1
 _C.TEST = CN()
 _C.TEST.EVAL_PERIOD = 0
 _C.TEST.GT_SCALE = False
+# evaluators run by inference_on_dataset (projects/*/configs/Base.yaml: EVALUATORS); DATASETS.TEST.PREPROCESS names the test-time preprocess
+# steps whose backward() chain the evaluators fold into their index maps (MonoDepth2: Resize; Supervised: KBCrop)
+_C.EVALUATORS = ("kitti_evaluator", "kitti_evaluator_0_30", "kitti_evaluator_30_50", "kitti_evaluator_50_80")
+_C.DATASETS = CN()
+_C.DATASETS.TEST = CN()
+_C.DATASETS.TEST.PREPROCESS = [{"NAME": "Resize"}]
 _C.DATALOADER = CN()
 _C.DATALOADER.NUM_WORKERS = 4
 _C.OUTPUT_DIR = "./output"

@@ -126,6 +126,58 @@ class HipTrainer:
         for g, lr in zip(self.groups, lrs):
             g.lr = float(lr)
 
+    # ---- optimizer state in torch.optim.Adam/AdamW's state_dict layout, so that it travels through the reference's checkpoints
+    # (DetectionCheckpointer(model, dir, optimizer=...) of projects/*/train.py): parameters are numbered group by group in
+    # registration order; every parameter carries {'step', 'exp_avg', 'exp_avg_sq'}.  'param_names' is an addition that lets a load
+    # match by name when the numbering differs (the reference's encoder group also holds the unused fc.weight / fc.bias).
+    def state_dict(self):
+        state, groups, idx, off = {}, [], 0, 0
+        for g in self.groups:
+            ids = []
+            for _, p in g.named_params:
+                n = p.numel()
+                if self.t > 0:
+                    state[idx] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[off:off + n].view(p.shape).detach().cpu().clone(),
+                                  "exp_avg_sq": self.v[off:off + n].view(p.shape).detach().cpu().clone()}
+                ids.append(idx)
+                idx += 1
+                off += n
+            groups.append({"lr": g.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": g.weight_decay, "amsgrad": False,
+                           "params": ids, "param_names": [n for n, _ in g.named_params], "name": g.name})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        """Accepts what state_dict() writes and what torch.optim.Adam(W).state_dict() of the reference's optimizer writes (same groups,
+        same order).  Within a group parameters are matched by 'param_names' when present, otherwise by position; entries whose shape
+        does not match the parameter at that position are a ValueError (nothing is loaded silently into the wrong tensor)."""
+        their_groups = sd["param_groups"]
+        if len(their_groups) != len(self.groups):
+            raise ValueError(f"optimizer checkpoint has {len(their_groups)} parameter groups, this trainer {len(self.groups)}")
+        state = {int(k): v for k, v in sd["state"].items()}
+        steps, off = [], 0
+        self.m.zero_()
+        self.v.zero_()
+        for g, tg in zip(self.groups, their_groups):
+            names = tg.get("param_names")
+            by_name = dict(zip(names, tg["params"])) if names else None
+            for pos, (n, p) in enumerate(g.named_params):
+                k = p.numel()
+                pid = by_name.get(n) if by_name is not None else (tg["params"][pos] if pos < len(tg["params"]) else None)
+                ent = state.get(pid) if pid is not None else None
+                if ent is not None:
+                    if tuple(ent["exp_avg"].shape) != tuple(p.shape):
+                        raise ValueError(f"optimizer state {pid} has shape {tuple(ent['exp_avg'].shape)}, parameter '{n}' {tuple(p.shape)}")
+                    self.m[off:off + k].copy_(ent["exp_avg"].reshape(-1).to(self.m))
+                    self.v[off:off + k].copy_(ent["exp_avg_sq"].reshape(-1).to(self.v))
+                    steps.append(int(float(ent["step"])))
+                off += k
+            g.lr, g.weight_decay = float(tg.get("lr", g.lr)), float(tg.get("weight_decay", g.weight_decay))
+        if steps and min(steps) != max(steps):
+            raise ValueError("per-parameter step counts differ; the fused Adam kernel keeps one step count for all parameters")
+        self.t = steps[0] if steps else 0
+        self.seg_lr.copy_(torch.tensor([g.lr for g in self.groups], dtype=torch.float32))
+        self.seg_wd.copy_(torch.tensor([g.weight_decay for g in self.groups], dtype=torch.float32))
+
     def _fwd_bwd(self, batch):
         self.gflat.zero_()
         if self._packer is not None:
@@ -217,6 +269,12 @@ class HipTrainer:
     def capture(self, batch, warmup=3):
         """Warm up eagerly (sets kernel attributes, fills the allocator), then capture zero-grad + forward + backward."""
         self._static_batch = self._to_static(batch)
+        # the warm-up steps and the capture pass must leave no trace in the model: BatchNorm running statistics (updated by every
+        # training-mode forward) and the host-side batch counters are put back afterwards, so step k of a captured run sees exactly
+        # the buffers step k of an eager run sees (and a resumed run continues from what the checkpoint held)
+        self._bns = [m for m in self.model.modules() if hasattr(m, "_pending_batches")]
+        kept_buffers = [b.detach().clone() for b in self.model.buffers()]
+        kept_counts = [m._pending_batches for m in self._bns]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -233,6 +291,11 @@ class HipTrainer:
             self._graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_b, pool=self._graph.pool()):
                 self._backward_rest()
+        with torch.no_grad():
+            for b, k in zip(self.model.buffers(), kept_buffers):
+                b.copy_(k)
+        for m, k in zip(self._bns, kept_counts):
+            m._pending_batches = k
         return self
 
     def step(self, batch):
@@ -242,6 +305,8 @@ class HipTrainer:
                 self.capture(batch)
             self._copy_into_static(batch)
             self._graph.replay()
+            for m in self._bns:                     # the replay runs no Python forward: count the batch for num_batches_tracked here
+                m._pending_batches += 1
             loss_dict = self._static_out
         else:
             loss_dict = self._fwd_bwd(batch)

@@ -1,0 +1,124 @@
+"""KITTI depth evaluators on the GPU (contract: detectron2/evaluation/depth_evaluation.py:L56-160).
+
+``kitti_evaluator`` and its three range variants keep the reference's names, constructor ``(cfg, output_folder)``, ``process(inputs, outputs)``
+inputs (``inputs['depth_orig']`` ground truth at original resolution, ``inputs['metadata']``, ``outputs['depth_pred']`` [B,1,h,w]) and the
+``{tag: {abs_rel, sq_rel, rms, log_rms, d1, d2, d3}}`` result.  Per image one ``sde_depth_metrics`` call replaces the numpy body of the loop:
+the nearest-neighbour resize back to the original size (and the crop un-pastes) are two index maps the kernel reads the network output
+through, the Garg crop is a window, the optional median scaling and the nine error sums run on the device, and nothing is copied to the host
+until ``evaluate()``.  The four evaluators of a config share nothing but the inputs; each image costs them 4 x 3 launches.
+
+Not built: ``kitti_depth_saver`` (PNG writing through cv2; I/O, not compute)."""
+import logging
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ..hip import evaluation as HE
+from .evaluator import EVALUATOR_REGISTRY, DatasetEvaluator
+
+METRIC_NAMES = ("silog", "log10", "abs_rel", "sq_rel", "rms", "log_rms", "d1", "d2", "d3")
+
+
+def crop_window(kind, h, w):
+    """garg_crop / eigen_crop (L16-27) as the window [y0, y1) x [x0, x1) they slice out of an h x w map."""
+    fy0, fy1, fx0, fx1 = {"garg": (0.40810811, 0.99189189, 0.03594771, 0.96405229),
+                          "eigen": (0.3324324, 0.91351351, 0.0359477, 0.96405229), None: (0.0, 1.0, 0.0, 1.0)}[kind]
+    return int(fy0 * h), int(fy1 * h), int(fx0 * w), int(fx1 * w)
+
+
+def _nearest(src, dst):
+    """Source index per destination index of cv2.resize(INTER_NEAREST): floor(x * (1 / (dst/src))) in doubles, clamped (OpenCV resizeNN)."""
+    step = 1.0 / (float(dst) / float(src))
+    return np.minimum(np.floor(np.arange(dst, dtype=np.float64) * step).astype(np.int64), src - 1).astype(np.int32)
+
+
+def backward_maps(pred_hw, metadata, chain):
+    """The postprocess.backward() chain (augmentation.py: Resize L163-166, KBCrop L67-74, CropTopTo L113-120) as (ymap, xmap) int32 arrays:
+    which network-output row / column each row / column of the restored full-size map shows; -1 where the reference pastes zeros."""
+    rows, cols = np.arange(pred_hw[0], dtype=np.int32), np.arange(pred_hw[1], dtype=np.int32)
+    for step in reversed(list(chain)):
+        if step == "Resize":
+            rows = rows[_nearest(rows.size, int(metadata["h_before_resize"]))]
+            cols = cols[_nearest(cols.size, int(metadata["w_before_resize"]))]
+        elif step == "KBCrop":
+            big_r = np.full(int(metadata["h_before_kb_crop"]), -1, np.int32)
+            big_c = np.full(int(metadata["w_before_kb_crop"]), -1, np.int32)
+            oy, ox = int(metadata["kb_y_start"]), int(metadata["kb_x_start"])
+            big_r[oy:oy + rows.size], big_c[ox:ox + cols.size] = rows, cols
+            rows, cols = big_r, big_c
+        elif step == "CropTopTo":
+            big_r = np.full(int(metadata["h_before_crop"]), -1, np.int32)
+            big_r[int(metadata["crop_y_start"]):] = rows
+            rows = big_r
+    return rows, cols
+
+
+@EVALUATOR_REGISTRY.register()
+class kitti_evaluator(DatasetEvaluator):
+    def __init__(self, cfg, output_folder=None):
+        super().__init__(cfg)
+        self._logger = logging.getLogger(__name__)
+        self.min_depth, self.max_depth = 1e-3, 80
+        self.garg_crop, self.eigen_crop = True, False
+        self.use_gt_scale = bool(cfg.TEST.GT_SCALE)
+        self.tag = "kitti evaluator"
+        self.metrics = []
+        self._maps = {}
+
+    def reset(self):
+        self.metrics = []
+
+    def _device_maps(self, pred_hw, gt_hw, meta, device):
+        chain = self.preprocess_chain
+        key = (pred_hw, gt_hw, tuple(chain), tuple(sorted((k, v) for k, v in meta.items() if isinstance(v, (int, np.integer)))))
+        hit = self._maps.get(key)
+        if hit is None:
+            if chain:
+                rows, cols = backward_maps(pred_hw, meta, chain)
+            else:                                   # no chain configured: nearest resize straight to the ground-truth size
+                rows, cols = _nearest(pred_hw[0], gt_hw[0]), _nearest(pred_hw[1], gt_hw[1])
+            if (rows.size, cols.size) != tuple(gt_hw):
+                raise ValueError(f"restored prediction is {rows.size}x{cols.size}, ground truth {gt_hw[0]}x{gt_hw[1]}")
+            hit = (torch.from_numpy(rows).to(device), torch.from_numpy(cols).to(device))
+            self._maps[key] = hit
+        return hit
+
+    def process(self, inputs, outputs):
+        preds = outputs["depth_pred"]
+        metas = inputs.get("metadata") or [{}] * len(preds)
+        for gt, pred, meta in zip(inputs["depth_orig"], preds, metas):
+            pred = pred.detach().squeeze().float().contiguous()
+            gt = torch.as_tensor(np.ascontiguousarray(gt) if isinstance(gt, np.ndarray) else gt).squeeze().to(pred.device, torch.float32).contiguous()
+            rows, cols = self._device_maps(tuple(pred.shape), tuple(gt.shape), meta, pred.device)
+            kind = "garg" if self.garg_crop else ("eigen" if self.eigen_crop else None)
+            self.metrics.append(HE.depth_metrics(pred, gt, rows, cols, crop_window(kind, *gt.shape), self.min_depth, self.max_depth, self.use_gt_scale))
+
+    def evaluate(self):
+        rows = torch.stack(self.metrics).cpu().numpy() if self.metrics else np.zeros((0, HE.NOUT))      # the run's only device -> host copy
+        rows = rows[rows[:, 9] > 0][:, :9]                                                            # images without a valid pixel are skipped (L102)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            gathered = [None] * dist.get_world_size()
+            dist.all_gather_object(gathered, rows)
+            if dist.get_rank() != 0:
+                return {}
+            rows = np.concatenate(gathered, 0)
+        if rows.shape[0] == 0:
+            self._logger.warning("[DepthEvaluator] Did not receive valid predictions.")
+            return {}
+        mean = rows.mean(0)
+        self._logger.info("%s%s: %s", self.tag, " w/ gt scale" if self.use_gt_scale else "",
+                          ", ".join(f"{n} {mean[i]:.3f}" for i, n in enumerate(METRIC_NAMES) if i >= 2))
+        return {self.tag: {n: float(mean[i]) for i, n in enumerate(METRIC_NAMES) if i >= 2}}
+
+
+def _ranged(name, lo, hi, tag):
+    def __init__(self, cfg, output_folder=None):
+        kitti_evaluator.__init__(self, cfg, output_folder)
+        self.min_depth, self.max_depth, self.tag = lo, hi, tag
+    return EVALUATOR_REGISTRY.register(type(name, (kitti_evaluator,), {"__init__": __init__, "__doc__": f"kitti_evaluator restricted to {lo} < gt < {hi}"}))
+
+
+kitti_evaluator_0_30 = _ranged("kitti_evaluator_0_30", 1e-3, 30, "kitti evaluator (0-30m)")
+kitti_evaluator_30_50 = _ranged("kitti_evaluator_30_50", 30, 50, "kitti evaluator (30-50m)")
+kitti_evaluator_50_80 = _ranged("kitti_evaluator_50_80", 50, 80, "kitti evaluator (50-80m)")

@@ -59,6 +59,10 @@ class HipBatchNorm2d(nn.Module):
         self.flush_counters()
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_batches = 0                  # the loaded num_batches_tracked is the whole count
+        super()._load_from_state_dict(*args, **kwargs)
+
     def forward(self, y, stats, residual=None, relu=True):
         if self.training:
             self._pending_batches += 1

@@ -58,17 +58,19 @@ class PackNet01(nn.Module):
         self.version = cfg.MODEL.DEPTH_NET.VERSION[1:]
         if self.version not in ("A", "B"):
             raise ValueError("Unknown MonoDepth2 version {}".format(self.version))
+        # registration order = the reference's (L60-100), so that parameter indices of an optimizer checkpoint line up
         self.pre_calc = L01.Conv2D(3, WIDTH[0], 5, 1)
+        for lvl, k in PACK_KERNEL.items():
+            setattr(self, f"pack{lvl}", L01.PackLayerConv3d(WIDTH[lvl], k))
         self.conv1 = L01.Conv2D(WIDTH[0], WIDTH[1], 7, 1)
         for lvl, blocks in RES_BLOCKS.items():
             setattr(self, f"conv{lvl}", L01.ResidualBlock(WIDTH[lvl - 1], WIDTH[lvl], blocks, 1, dropout=0.0))
-        for lvl, k in PACK_KERNEL.items():
-            setattr(self, f"pack{lvl}", L01.PackLayerConv3d(WIDTH[lvl], k))
-        for lvl, (up_w, iconv_in) in _decoder_widths(self.version).items():
-            below = WIDTH[min(lvl + 1, 5)]                       # what feeds the unpack: iconv of the level below (pack5 at the bottom)
-            setattr(self, f"unpack{lvl}", L01.UnpackLayerConv3d(below, up_w, 3))
-            setattr(self, f"iconv{lvl}", L01.Conv2D(iconv_in, WIDTH[lvl], 3, 1))
-        for lvl in DISP_LEVELS:
+        dec = _decoder_widths(self.version)
+        for lvl in range(5, 0, -1):                                # unpack input: iconv of the level below (pack5 at the bottom)
+            setattr(self, f"unpack{lvl}", L01.UnpackLayerConv3d(WIDTH[min(lvl + 1, 5)], dec[lvl][0], 3))
+        for lvl in range(5, 0, -1):
+            setattr(self, f"iconv{lvl}", L01.Conv2D(dec[lvl][1], WIDTH[lvl], 3, 1))
+        for lvl in reversed(DISP_LEVELS):
             setattr(self, f"disp{lvl}_layer", L01.InvDepth(WIDTH[lvl], out_channels=1))
         self.max_depth = cfg.MODEL.MAX_DEPTH
         self.upsample_depth = cfg.MODEL.DEPTH_NET.UPSAMPLE_DEPTH

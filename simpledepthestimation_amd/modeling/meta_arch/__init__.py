@@ -1,3 +1,5 @@
-from .build import META_ARCH_REGISTRY, build_model  # noqa: F401
-from .Supervised import SupDepthModel  # noqa: F401
-from .MonoDepth2 import MonoDepth2Model  # noqa: F401
+"""Meta architectures of the hot path.  Importing the two model modules registers their classes in META_ARCH_REGISTRY."""
+from . import MonoDepth2 as _mono, Supervised as _sup, build as _build
+
+META_ARCH_REGISTRY, build_model = _build.META_ARCH_REGISTRY, _build.build_model
+SupDepthModel, MonoDepth2Model = _sup.SupDepthModel, _mono.MonoDepth2Model

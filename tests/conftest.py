@@ -48,3 +48,8 @@ def pack():
 @pytest.fixture(scope="session")
 def opt():
     return _Golden(os.path.join(GOLDEN, "options.npz"))
+
+
+@pytest.fixture(scope="session")
+def evg():
+    return _Golden(os.path.join(GOLDEN, "eval.npz"))

@@ -41,6 +41,7 @@ def test_python_binding_covers_header():
         import simpledepthestimation_amd.hip.nn  # noqa: F401
     except ImportError:
         pass
+    import simpledepthestimation_amd.hip.evaluation  # noqa: F401
     bound = set(L._PROTOS) | {"sde_last_error"}
     missing = [s for s in declared_symbols() if s not in bound]
     assert not missing, f"no ctypes prototype for: {missing}"

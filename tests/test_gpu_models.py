@@ -250,9 +250,12 @@ def test_graph_replay_equals_eager():
         model = build("SupDepthModel", 18, sd).train()
         tr = supervised_trainer(model, make_cfg("SupDepthModel", 18), use_graph=use_graph)
         losses = [float(tr.step(clone_batch(batch))["silog_loss"]) for _ in range(3)]
-        res.append((losses, tr.pflat.clone()))
+        res.append((losses, tr.pflat.clone(), {k: v.clone() for k, v in model.state_dict().items()}))
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
+    for k, v in res[0][2].items():               # buffers too: the capture's warm-up steps leave no trace in the BatchNorm running statistics
+        assert torch.equal(v, res[1][2][k]), k
+    assert int(res[1][2]["depth_net.encoder.encoder.bn1.num_batches_tracked"]) == 3
 
 
 @pytest.mark.parametrize("version", ["A", "B"])
@@ -362,3 +365,28 @@ def test_monodepth2_loss_clip(opt, red):
         n = k[len(tag) + 7:]
         g = named[n].grad.norm().item()
         assert abs(g - float(opt[k])) < 2e-2 * float(opt[k]) + 1e-8, f"grad norm of {n}: {g} vs {float(opt[k])}"
+
+
+def test_checkpoint_resume_continues_bit_exactly(tmp_path):
+    """Save (model + fused-Adam state) after 2 steps, resume in a freshly built model/trainer: steps 3-4 reproduce the uninterrupted run bit
+    for bit, graph replay included (the replayed graph reads the flat buffers the loader writes into)."""
+    from simpledepthestimation_amd.checkpoint import DetectionCheckpointer, PeriodicCheckpointer
+    from simpledepthestimation_amd.engine.trainer import monodepth2_trainer
+    cfg = make_cfg("MonoDepth2Model", 18)
+    batch = mono_batch(2, 64, 192, 12)
+    dbatch = {k: ([x.to(dev) for x in v] if isinstance(v, list) else v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    model = build("MonoDepth2Model", 18, OM.init_state_dict(18, with_pose=True, seed=21)).train()
+    tr = monodepth2_trainer(model, cfg, use_graph=True)
+    for _ in range(2):
+        tr.step(clone_batch(dbatch))
+    PeriodicCheckpointer(DetectionCheckpointer(model, str(tmp_path), optimizer=tr), 1).step(1)
+    want = [float(tr.step(clone_batch(dbatch))["rec_loss"]) for _ in range(2)]
+    model2 = build("MonoDepth2Model", 18, OM.init_state_dict(18, with_pose=True, seed=99)).train()        # different weights on purpose
+    tr2 = monodepth2_trainer(model2, cfg, use_graph=True)
+    rest = DetectionCheckpointer(model2, str(tmp_path), optimizer=tr2).resume_or_load("", resume=True)
+    assert rest == {"iteration": 1} and tr2.t == 2
+    got = [float(tr2.step(clone_batch(dbatch))["rec_loss"]) for _ in range(2)]
+    assert got == want, (got, want)
+    assert torch.equal(tr.pflat, tr2.pflat) and torch.equal(tr.m, tr2.m) and torch.equal(tr.v, tr2.v)
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), k
