@@ -256,13 +256,14 @@ int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const lo
  * scaling of TEST.GT_SCALE (L91-93) and the postprocess.backward() chain folded into two index maps: ymap[gh], xmap[gw] give the
  * prediction row / column every ground-truth row / column reads (Resize.backward = cv2 INTER_NEAREST, augmentation.py:L163-166; the crop
  * un-pastes of L67-74, L113-120; -1 = outside the prediction: value 0).  pred [ph,pw], gt [gh,gw] fp32, maps int32, all device memory.
- * part: workspace [sde_depth_metrics_num_blocks(y1-y0, x1-x0)][SDE_EVAL_NSUM] doubles; med: workspace [3] floats.
+ * part: workspace [sde_depth_metrics_num_blocks(y1-y0, x1-x0)][SDE_EVAL_NSUM] doubles; med: workspace of 4 x 4 bytes, ZEROED by the caller;
+ * keys: workspace of 2 * (y1-y0) * (x1-x0) uint32 for the median selection (may be NULL when gt_scale == 0).
  * out[12] doubles = silog, log10, abs_rel, sq_rel, rms, log_rms, d1, d2, d3 (compute_errors' return order), then the number of valid pixels
  * (0: the reference skips the image, L102), median(gt), median(pred) (0 when gt_scale == 0).  No host synchronisation. */
 #define SDE_EVAL_NSUM 11
 int sde_depth_metrics_num_blocks(int crop_h, int crop_w);
 int sde_depth_metrics(const float* pred, int ph, int pw, const float* gt, int gh, int gw, const int* ymap, const int* xmap, int y0, int y1,
-                      int x0, int x1, float min_depth, float max_depth, int gt_scale, double* part, float* med, double* out,
+                      int x0, int x1, float min_depth, float max_depth, int gt_scale, double* part, float* med, unsigned* keys, double* out,
                       sde_stream_t stream);
 
 #ifdef __cplusplus

@@ -1,8 +1,9 @@
 // KITTI depth metrics on the GPU: the per-image body of kitti_evaluator.process
-// (detectron2/evaluation/depth_evaluation.py:L74-104) + compute_errors (L30-53) as three launches per image, no host round trip:
+// (detectron2/evaluation/depth_evaluation.py:L74-104) + compute_errors (L30-53) as two launches per image (four with median scaling), no host round trip:
 //
-//   1. eval_median_kernel   (only with TEST.GT_SCALE) exact medians of gt[m] and pred[m], m = 1e-3 < gt < 80 inside the crop window, by a
-//                           4-pass 8-bit radix select over order-preserving float keys (np.median: mean of the two middle elements);
+//   1. eval_compact_kernel + eval_select_kernel (only with TEST.GT_SCALE) exact medians of gt[m] and pred[m], m = 1e-3 < gt < 80 inside the
+//                           crop window: the valid pixels' order-preserving float keys are compacted by the whole grid, then a 4-pass 8-bit
+//                           radix select finds the two middle ranks (np.median: mean of the two middle elements);
 //   2. eval_sums_kernel     one pass over the crop window: per-pixel terms in fp32 in numpy's operation order, accumulated in fp64;
 //   3. eval_finalize_kernel fixed-order sum of the per-workgroup partials -> the 9 metrics.
 //
@@ -36,43 +37,113 @@ __device__ __forceinline__ unsigned fkey(float f) {
 }
 __device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-// grid = 2 workgroups of 1024: blockIdx.x == 0 selects over gt, == 1 over the prediction; med[which], med[2] = count
-__global__ void __launch_bounds__(1024) eval_median_kernel(EvalP p, float* med) {
-    __shared__ unsigned hist[2][256];
-    __shared__ unsigned s_prefix[2], s_rank[2], s_n;
-    const int which = blockIdx.x, tid = threadIdx.x;
+// Median step 1: every workgroup appends the order-preserving keys of the valid pixels (1e-3 < gt < 80 inside the window) of its 1024-pixel
+// chunks to two dense arrays (gt keys, prediction keys).  Four independent pixels per thread, ballot prefix sums inside a wave, ONE global
+// atomic per chunk reserves the slots.  The order of the dense arrays is arbitrary -- a median does not depend on it.  cnt = number of keys
+// (zeroed by the caller).
+__global__ void __launch_bounds__(256) eval_compact_kernel(EvalP p, unsigned* keys_g, unsigned* keys_p, unsigned* cnt) {
+    __shared__ unsigned wave_tot[4], s_base;
     const int cw = p.x1 - p.x0, npx = (p.y1 - p.y0) * cw;
-    unsigned prefix[2] = {0u, 0u}, rank[2] = {0u, 0u};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int chunk = blockIdx.x; chunk * 1024 < npx; chunk += gridDim.x) {
+        float g[4]; int yy[4], xx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = chunk * 1024 + j * 256 + threadIdx.x;
+            const int ic = i < npx ? i : npx - 1;
+            yy[j] = p.y0 + ic / cw; xx[j] = p.x0 + ic % cw;
+            g[j] = i < npx ? p.gt[(size_t)yy[j] * p.gw + xx[j]] : 0.f;
+        }
+        unsigned long long m[4];
+        unsigned tot = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m[j] = __ballot(g[j] > 1e-3f && g[j] < 80.f); tot += (unsigned)__popcll(m[j]); }
+        if (lane == 0) wave_tot[wave] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = atomicAdd(cnt, wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3]);
+        __syncthreads();
+        unsigned at = s_base;
+        for (int w = 0; w < wave; ++w) at += wave_tot[w];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if ((m[j] >> lane) & 1ull) {
+                const unsigned slot = at + (unsigned)__popcll(m[j] & ((1ull << lane) - 1ull));
+                keys_g[slot] = fkey(g[j]); keys_p[slot] = fkey(pred_at(p, yy[j], xx[j]));
+            }
+            at += (unsigned)__popcll(m[j]);
+        }
+        __syncthreads();
+    }
+}
+
+// Median step 2: grid = 2 workgroups of 1024 (blockIdx.x == 0: gt keys, 1: prediction keys).  4-pass, 8-bit, MSB-first radix select of the two
+// middle ranks over the dense keys; LDS histograms.  In the first pass nearly every key of a wave falls into the same two or three bins (sign +
+// exponent bits), so lanes with equal bins are counted with one atomic per distinct bin; the lower bytes are spread and use plain LDS atomics.
+__global__ void __launch_bounds__(1024) eval_select_kernel(const unsigned* keys_g, const unsigned* keys_p, const unsigned* cnt, float* med) {
+    __shared__ unsigned hist[2][256];
+    __shared__ unsigned s_prefix[2], s_rank[2];
+    const int which = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const unsigned* keys = which == 0 ? keys_g : keys_p;
+    const unsigned n = *cnt;
+    if (n == 0u) {                                   // nothing valid: the evaluator skips the image (count 0 in out[9])
+        if (tid == 0) { med[which] = 0.f; med[2] = 0.f; }
+        return;
+    }
+    unsigned prefix[2] = {0u, 0u}, rank[2] = {(n - 1) / 2, n / 2};
     unsigned mask = 0u;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         for (int i = tid; i < 512; i += 1024) hist[i >> 8][i & 255] = 0u;
         __syncthreads();
-        for (int i = tid; i < npx; i += 1024) {
-            const int y = p.y0 + i / cw, x = p.x0 + i % cw;
-            const float g = p.gt[(size_t)y * p.gw + x];
-            if (!(g > 1e-3f && g < 80.f)) continue;
-            const unsigned k = fkey(which == 0 ? g : pred_at(p, y, x));
-            const unsigned b = (k >> shift) & 255u;
-            if ((k & mask) == prefix[0]) atomicAdd(&hist[0][b], 1u);
-            if ((k & mask) == prefix[1]) atomicAdd(&hist[1][b], 1u);
+        // 8 independent loads per thread and trip: a single workgroup has no other way to hide the memory latency
+        for (unsigned base = 0; base < n; base += 8192u) {
+            unsigned kk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned i = base + j * 1024u + tid;
+                kk[j] = i < n ? keys[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool in = base + j * 1024u + tid < n;
+                const unsigned k = kk[j], b = (k >> shift) & 255u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bool mine = in && (k & mask) == prefix[h];
+                    if (pass == 0) {
+                        unsigned long long todo = __ballot(mine);
+                        while (todo) {
+                            const int leader = __ffsll((long long)todo) - 1;
+                            const unsigned lb = __shfl(b, leader, 64);
+                            const unsigned long long same = __ballot(mine && b == lb);
+                            if (lane == leader) atomicAdd(&hist[h][lb], (unsigned)__popcll(same));
+                            todo &= ~same;
+                            if (b == lb) mine = false;
+                        }
+                    } else if (mine) {
+                        atomicAdd(&hist[h][b], 1u);
+                    }
+                }
+            }
         }
         __syncthreads();
-        if (tid < 2) {
-            if (pass == 0) {
-                unsigned n = 0;
-                for (int b = 0; b < 256; ++b) n += hist[0][b];
-                if (tid == 0) s_n = n;
-                rank[tid] = n ? (tid == 0 ? (n - 1) / 2 : n / 2) : 0u;
+        if (tid < 128) {        // one wave per tracked rank: 4 bins per lane, shuffle scan over the lanes, the lane whose range holds the rank resolves it
+            const int h = tid >> 6;
+            const unsigned c0 = hist[h][4 * lane], c1 = hist[h][4 * lane + 1], c2 = hist[h][4 * lane + 2], c3 = hist[h][4 * lane + 3];
+            const unsigned sum = c0 + c1 + c2 + c3;
+            unsigned incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
             }
-            unsigned r = rank[tid], b = 0;
-            for (; b < 255u; ++b) {
-                const unsigned c = hist[tid][b];
-                if (r < c) break;
-                r -= c;
+            const unsigned excl = incl - sum, r = rank[h];
+            if (r >= excl && r < incl) {             // exactly one lane: the rank is below the number of keys that share the prefix
+                unsigned rr = r - excl, b = 4u * lane;
+                if (rr >= c0) { rr -= c0; ++b; if (rr >= c1) { rr -= c1; ++b; if (rr >= c2) { rr -= c2; ++b; } } }
+                s_prefix[h] = prefix[h] | (b << shift);
+                s_rank[h] = rr;
             }
-            s_prefix[tid] = prefix[tid] | (b << shift);
-            s_rank[tid] = r;
         }
         __syncthreads();
         prefix[0] = s_prefix[0]; prefix[1] = s_prefix[1];
@@ -83,7 +154,7 @@ __global__ void __launch_bounds__(1024) eval_median_kernel(EvalP p, float* med) 
     if (tid == 0) {
         const float a = fkey_inv(prefix[0]), b = fkey_inv(prefix[1]);
         med[which] = (a + b) * 0.5f;             // np.median of float32: fp32 mean of the two middle elements
-        if (which == 0) med[2] = (float)s_n;
+        if (which == 0) med[2] = (float)n;
     }
 }
 
@@ -130,14 +201,16 @@ __global__ void __launch_bounds__(256) eval_sums_kernel(EvalP p, const float* me
     if (threadIdx.x < NSUM) part[(size_t)blockIdx.x * NSUM + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// out[0..8] = silog, log10, abs_rel, sq_rel, rms, log_rms, d1, d2, d3 (compute_errors' return order), out[9] = n, out[10..11] = medians
-__global__ void eval_finalize_kernel(const double* part, int nblk, const float* med, int gt_scale, double* out) {
+// out[0..8] = silog, log10, abs_rel, sq_rel, rms, log_rms, d1, d2, d3 (compute_errors' return order), out[9] = n, out[10..11] = medians.
+// NSUM waves: wave k adds column k of the partials (lanes stride the rows, then a fixed-order butterfly), thread 0 forms the metrics.
+__global__ void __launch_bounds__(64 * NSUM) eval_finalize_kernel(const double* part, int nblk, const float* med, int gt_scale, double* out) {
     __shared__ double tot[NSUM];
-    if (threadIdx.x < NSUM) {
-        double a = 0.0;
-        for (int b = 0; b < nblk; ++b) a += part[(size_t)b * NSUM + threadIdx.x];
-        tot[threadIdx.x] = a;
-    }
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double a = 0.0;
+    for (int b = lane; b < nblk; b += 64) a += part[(size_t)b * NSUM + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) tot[k] = a;
     __syncthreads();
     if (threadIdx.x == 0) {
         const double n = tot[0], inv = n > 0 ? 1.0 / n : 0.0;
@@ -167,22 +240,27 @@ int sde_depth_metrics_num_blocks(int crop_h, int crop_w) {
 }
 
 int sde_depth_metrics(const float* pred, int ph, int pw, const float* gt, int gh, int gw, const int* ymap, const int* xmap, int y0, int y1,
-                      int x0, int x1, float min_depth, float max_depth, int gt_scale, double* part, float* med, double* out,
+                      int x0, int x1, float min_depth, float max_depth, int gt_scale, double* part, float* med, unsigned* keys, double* out,
                       sde_stream_t stream) {
     SDE_CHECK_ARG(pred && gt && ymap && xmap && part && med && out, "sde_depth_metrics: null pointer");
+    SDE_CHECK_ARG(!gt_scale || keys, "sde_depth_metrics: gt_scale needs the key workspace");
     SDE_CHECK_ARG(ph > 0 && pw > 0 && gh > 0 && gw > 0, "sde_depth_metrics: bad shape");
     SDE_CHECK_ARG(0 <= y0 && y0 < y1 && y1 <= gh && 0 <= x0 && x0 < x1 && x1 <= gw, "sde_depth_metrics: crop window [%d,%d)x[%d,%d) outside %dx%d",
                   y0, y1, x0, x1, gh, gw);
     EvalP p{pred, pw, gt, gw, ymap, xmap, y0, y1, x0, x1, min_depth, max_depth};
     hipStream_t s = (hipStream_t)stream;
-    if (gt_scale) {
-        hipLaunchKernelGGL(eval_median_kernel, dim3(2), dim3(1024), 0, s, p, med);
-        SDE_CHECK_LAUNCH("sde_depth_metrics/median");
-    }
     const int nb = sde_depth_metrics_num_blocks(y1 - y0, x1 - x0);
+    if (gt_scale) {
+        const size_t npx = (size_t)(y1 - y0) * (x1 - x0);
+        unsigned* cnt = reinterpret_cast<unsigned*>(med) + 3;        // zeroed by the caller together with med
+        hipLaunchKernelGGL(eval_compact_kernel, dim3(nb), dim3(256), 0, s, p, keys, keys + npx, cnt);
+        SDE_CHECK_LAUNCH("sde_depth_metrics/compact");
+        hipLaunchKernelGGL(eval_select_kernel, dim3(2), dim3(1024), 0, s, keys, keys + npx, cnt, med);
+        SDE_CHECK_LAUNCH("sde_depth_metrics/select");
+    }
     hipLaunchKernelGGL(eval_sums_kernel, dim3(nb), dim3(256), 0, s, p, med, gt_scale, part);
     SDE_CHECK_LAUNCH("sde_depth_metrics/sums");
-    hipLaunchKernelGGL(eval_finalize_kernel, dim3(1), dim3(64), 0, s, part, nb, med, gt_scale, out);
+    hipLaunchKernelGGL(eval_finalize_kernel, dim3(1), dim3(64 * NSUM), 0, s, part, nb, med, gt_scale, out);
     SDE_CHECK_LAUNCH("sde_depth_metrics/finalize");
     return SDE_OK;
 }

@@ -8,7 +8,7 @@ from . import lib as L
 _P, _I, _F = c_void_p, c_int, L.c_float
 L.register_protos({
     "sde_depth_metrics_num_blocks": ([_I, _I], c_int),
-    "sde_depth_metrics": ([_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P], c_int),
+    "sde_depth_metrics": ([_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P], c_int),
 })
 NSUM = 11          # SDE_EVAL_NSUM
 NOUT = 12
@@ -25,9 +25,10 @@ def depth_metrics(pred, gt, ymap, xmap, window, min_depth, max_depth, gt_scale):
     lib = L.lib()
     dev = gt.device
     part = torch.empty(lib.sde_depth_metrics_num_blocks(y1 - y0, x1 - x0) * NSUM, device=dev, dtype=torch.float64)
-    med = torch.zeros(3, device=dev, dtype=torch.float32)
+    med = torch.zeros(4, device=dev, dtype=torch.float32)           # medians, key count (float), key counter (uint32): zeroed
+    keys = torch.empty(2 * (y1 - y0) * (x1 - x0), device=dev, dtype=torch.int32) if gt_scale else None
     out = torch.empty(NOUT, device=dev, dtype=torch.float64)
     L.check(lib.sde_depth_metrics(L.ptr(pred), pred.shape[0], pred.shape[1], L.ptr(gt), gt.shape[0], gt.shape[1], L.ptr(ymap), L.ptr(xmap), y0, y1, x0, x1,
-                                  float(min_depth), float(max_depth), int(bool(gt_scale)), L.ptr(part), L.ptr(med), L.ptr(out), L.stream()),
+                                  float(min_depth), float(max_depth), int(bool(gt_scale)), L.ptr(part), L.ptr(med), L.ptr(keys), L.ptr(out), L.stream()),
             "sde_depth_metrics")
     return out
