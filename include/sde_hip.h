@@ -257,7 +257,9 @@ int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const lo
  * prediction row / column every ground-truth row / column reads (Resize.backward = cv2 INTER_NEAREST, augmentation.py:L163-166; the crop
  * un-pastes of L67-74, L113-120; -1 = outside the prediction: value 0).  pred [ph,pw], gt [gh,gw] fp32, maps int32, all device memory.
  * part: workspace [sde_depth_metrics_num_blocks(y1-y0, x1-x0)][SDE_EVAL_NSUM] doubles; med: workspace of 4 x 4 bytes, ZEROED by the caller;
- * keys: workspace of 2 * (y1-y0) * (x1-x0) uint32 for the median selection (may be NULL when gt_scale == 0).
+ * keys: workspace of 2 * (y1-y0) * (x1-x0) uint32 for the median selection (needed only when gt_scale == 1).
+ * gt_scale: 0 = no scaling; 1 = compute the medians into med[0..1], then scale; 2 = med[0..1] already hold the medians of this image and
+ * window (the evaluators of one config share them: same mask, same crop).
  * out[12] doubles = silog, log10, abs_rel, sq_rel, rms, log_rms, d1, d2, d3 (compute_errors' return order), then the number of valid pixels
  * (0: the reference skips the image, L102), median(gt), median(pred) (0 when gt_scale == 0).  No host synchronisation. */
 #define SDE_EVAL_NSUM 11

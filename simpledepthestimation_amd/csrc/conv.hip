@@ -1433,7 +1433,12 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, wgrad_bmg(Cout) == 64 ? wgrad_bng() : 128);
     const int BR = d->dtype == SDE_BF16 ? 64 : 32;
     static const long target = [] { const char* e = getenv("SDE_WGRAD_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 256L; }();
-    long want = (target + tiles - 1) / tiles;               // default 256 (one workgroup per CU): measured best end to end -- every extra split is another fp32 slab through HBM
+    // layers whose slab is tiny (few output channels x few K columns) but whose pixel count is huge -- the full-resolution decoder tail -- are
+    // pure loader latency at one workgroup per CU; extra splits cost them almost nothing in slab traffic (SDE_WGRAD_SMALL_MULT x the target)
+    static const long small_kb = [] { const char* e = getenv("SDE_WGRAD_SMALL_KB"); const long v = e ? atol(e) : 0; return v > 0 ? v : 128L; }();
+    static const long small_mult = [] { const char* e = getenv("SDE_WGRAD_SMALL_MULT"); const long v = e ? atol(e) : 0; return v > 0 ? v : 1L; }();
+    const long tgt = ((long)Cout * Ktot * 4 <= (small_kb << 10) && M >= (1L << 18)) ? target * small_mult : target;
+    long want = (tgt + tiles - 1) / tiles;                  // default 256 (one workgroup per CU): measured best end to end -- every extra split is another fp32 slab through HBM
     const long max_by_rows = (M + 4 * BR - 1) / (4 * BR);   // at least 4 stages per split
     if (want > max_by_rows) want = max_by_rows;
     const long max_by_mem = (256L << 20) / ((long)Cout * Ktot * 4);   // slab <= 256 MiB

@@ -243,14 +243,15 @@ int sde_depth_metrics(const float* pred, int ph, int pw, const float* gt, int gh
                       int x0, int x1, float min_depth, float max_depth, int gt_scale, double* part, float* med, unsigned* keys, double* out,
                       sde_stream_t stream) {
     SDE_CHECK_ARG(pred && gt && ymap && xmap && part && med && out, "sde_depth_metrics: null pointer");
-    SDE_CHECK_ARG(!gt_scale || keys, "sde_depth_metrics: gt_scale needs the key workspace");
+    SDE_CHECK_ARG(gt_scale >= 0 && gt_scale <= 2, "sde_depth_metrics: gt_scale must be 0, 1 or 2");
     SDE_CHECK_ARG(ph > 0 && pw > 0 && gh > 0 && gw > 0, "sde_depth_metrics: bad shape");
     SDE_CHECK_ARG(0 <= y0 && y0 < y1 && y1 <= gh && 0 <= x0 && x0 < x1 && x1 <= gw, "sde_depth_metrics: crop window [%d,%d)x[%d,%d) outside %dx%d",
                   y0, y1, x0, x1, gh, gw);
     EvalP p{pred, pw, gt, gw, ymap, xmap, y0, y1, x0, x1, min_depth, max_depth};
     hipStream_t s = (hipStream_t)stream;
     const int nb = sde_depth_metrics_num_blocks(y1 - y0, x1 - x0);
-    if (gt_scale) {
+    if (gt_scale == 1) {        // gt_scale == 2: med[0..1] already hold this image's medians (another evaluator computed them)
+        SDE_CHECK_ARG(keys, "sde_depth_metrics: gt_scale = 1 needs the key workspace");
         const size_t npx = (size_t)(y1 - y0) * (x1 - x0);
         unsigned* cnt = reinterpret_cast<unsigned*>(med) + 3;        // zeroed by the caller together with med
         hipLaunchKernelGGL(eval_compact_kernel, dim3(nb), dim3(256), 0, s, p, keys, keys + npx, cnt);

@@ -5,7 +5,7 @@ inputs (``inputs['depth_orig']`` ground truth at original resolution, ``inputs['
 ``{tag: {abs_rel, sq_rel, rms, log_rms, d1, d2, d3}}`` result.  Per image one ``sde_depth_metrics`` call replaces the numpy body of the loop:
 the nearest-neighbour resize back to the original size (and the crop un-pastes) are two index maps the kernel reads the network output
 through, the Garg crop is a window, the optional median scaling and the nine error sums run on the device, and nothing is copied to the host
-until ``evaluate()``.  The four evaluators of a config share nothing but the inputs; each image costs them 4 x 3 launches.
+until ``evaluate()``.  The four evaluators of a config share the uploaded ground truth and the medians of an image through the ``outputs`` dict.
 
 Not built: ``kitti_depth_saver`` (PNG writing through cv2; I/O, not compute)."""
 import logging
@@ -87,12 +87,22 @@ class kitti_evaluator(DatasetEvaluator):
     def process(self, inputs, outputs):
         preds = outputs["depth_pred"]
         metas = inputs.get("metadata") or [{}] * len(preds)
-        for gt, pred, meta in zip(inputs["depth_orig"], preds, metas):
+        # the evaluators of a config see the same batch: ground truth is uploaded once, and the medians of GT scaling (same 1e-3..80 mask,
+        # same window) are selected once -- both are parked in the outputs dict for the evaluators that run after this one
+        shared = outputs.setdefault("_sde_eval_shared", {})
+        kind = "garg" if self.garg_crop else ("eigen" if self.eigen_crop else None)
+        for i, (gt, pred, meta) in enumerate(zip(inputs["depth_orig"], preds, metas)):
             pred = pred.detach().squeeze().float().contiguous()
-            gt = torch.as_tensor(np.ascontiguousarray(gt) if isinstance(gt, np.ndarray) else gt).squeeze().to(pred.device, torch.float32).contiguous()
-            rows, cols = self._device_maps(tuple(pred.shape), tuple(gt.shape), meta, pred.device)
-            kind = "garg" if self.garg_crop else ("eigen" if self.eigen_crop else None)
-            self.metrics.append(HE.depth_metrics(pred, gt, rows, cols, crop_window(kind, *gt.shape), self.min_depth, self.max_depth, self.use_gt_scale))
+            gt_dev = shared.get(("gt", i))
+            if gt_dev is None:
+                gt_dev = torch.as_tensor(np.ascontiguousarray(gt) if isinstance(gt, np.ndarray) else gt).squeeze().to(pred.device, torch.float32).contiguous()
+                shared["gt", i] = gt_dev
+            rows, cols = self._device_maps(tuple(pred.shape), tuple(gt_dev.shape), meta, pred.device)
+            res = HE.depth_metrics(pred, gt_dev, rows, cols, crop_window(kind, *gt_dev.shape), self.min_depth, self.max_depth, self.use_gt_scale,
+                                   med=shared.get(("med", i, kind)) if self.use_gt_scale else None)
+            if self.use_gt_scale:
+                shared["med", i, kind] = res.med
+            self.metrics.append(res)
 
     def evaluate(self):
         rows = torch.stack(self.metrics).cpu().numpy() if self.metrics else np.zeros((0, HE.NOUT))      # the run's only device -> host copy
