@@ -5,12 +5,12 @@ run() { name=$1; shift
   echo "$WL $name $(python -c "import json;d=json.load(open('gpurun_out/ab.json'));print(d['value'], d['ms_per_step'])")"
 }
 WL=sup_r50 run warmup SDE_X=0
-WL=sup_r50 run m1 SDE_WGRAD_SMALL_MULT=1
-WL=sup_r50 run m2 SDE_WGRAD_SMALL_MULT=2
-WL=sup_r50 run m3 SDE_WGRAD_SMALL_MULT=3
-WL=sup_r50 run m4 SDE_WGRAD_SMALL_MULT=4
-WL=sup_r50 run m1 SDE_WGRAD_SMALL_MULT=1
-WL=sup_r50 run m3 SDE_WGRAD_SMALL_MULT=3
-WL=sup_r50 run m3kb512 SDE_WGRAD_SMALL_MULT=3 SDE_WGRAD_SMALL_KB=512
-WL=mono_r18 run m1 SDE_WGRAD_SMALL_MULT=1
-WL=mono_r18 run m3 SDE_WGRAD_SMALL_MULT=3
+WL=sup_r50 run gemm SDE_NO_C1=1
+WL=sup_r50 run fwd SDE_C1_FWD=1
+WL=sup_r50 run fwd_dgrad SDE_C1_FWD=1 SDE_C1_DGRAD=1
+WL=sup_r50 run gemm SDE_NO_C1=1
+WL=sup_r50 run fwd SDE_C1_FWD=1
+WL=sup_r50 run fwd_dgrad SDE_C1_FWD=1 SDE_C1_DGRAD=1
+WL=mono_r18 run gemm SDE_NO_C1=1
+WL=mono_r18 run fwd SDE_C1_FWD=1
+WL=mono_r18 run fwd_dgrad SDE_C1_FWD=1 SDE_C1_DGRAD=1

@@ -55,6 +55,12 @@ CONV_CASES = [
     ("7x7_s2_stem", 2, 32, 64, 3, 64, 7, 2, 3, False, False, 0),
     ("refl_32_16_elu", 2, 16, 24, 32, 16, 3, 1, 1, True, True, 1),
     ("refl_16_1_head", 2, 16, 24, 16, 1, 3, 1, 1, True, True, 0),
+    # the four disparity heads (single output channel, N = 1 GEMMs): every Cin of the decoder, several thousand pixels, odd sizes, and the
+    # zero-padded form
+    ("refl_32_1_head", 2, 48, 64, 32, 1, 3, 1, 1, True, True, 0),
+    ("refl_64_1_head", 1, 13, 21, 64, 1, 3, 1, 1, True, True, 0),
+    ("refl_128_1_head", 2, 8, 12, 128, 1, 3, 1, 1, True, True, 0),
+    ("zero_16_1_head", 2, 16, 24, 16, 1, 3, 1, 1, False, True, 0),
     ("3x3_256_512_tinyM", 2, 6, 10, 256, 512, 3, 1, 1, False, False, 0),
     ("k5_s2_pose", 2, 24, 40, 16, 32, 5, 2, 2, False, True, 0),
     ("k7_s2_pose_in9", 2, 32, 64, 9, 16, 7, 2, 3, False, True, 0),
