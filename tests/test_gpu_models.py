@@ -2,6 +2,9 @@
 
 north_star tolerance: depth maps within 1e-4 relative in fp32.  Gradients are compared per parameter tensor by relative L2.
 """
+import os
+import shutil
+
 import pytest
 import torch
 
@@ -389,4 +392,51 @@ def test_checkpoint_resume_continues_bit_exactly(tmp_path):
     assert got == want, (got, want)
     assert torch.equal(tr.pflat, tr2.pflat) and torch.equal(tr.m, tr2.m) and torch.equal(tr.v, tr2.v)
     for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("arch", ["MonoDepth2Model", "SupDepthModel"])
+def test_training_loop_schedules_checkpoints_evaluates_and_resumes(tmp_path, arch):
+    """engine.loops.do_train (the projects' do_train on the HIP path): LR rules, LOG_PERIOD records in metrics.json, a checkpoint per epoch,
+    evaluation every epoch, and a run interrupted after epoch 0 that resumes to the same weights as the uninterrupted run, bit for bit."""
+    import json
+    import numpy as np
+    from simpledepthestimation_amd.engine.loops import do_train
+    from simpledepthestimation_amd.layers.fakeDDP import FakeDDP
+    sup = arch == "SupDepthModel"
+    mk = (lambda s: sup_batch(2, 64, 192, s)) if sup else (lambda s: mono_batch(2, 64, 192, s))
+    loader = [mk(60 + i) for i in range(3)]
+    rng = np.random.default_rng(1)
+    test_loader = [{"img": loader[0]["img"], "metadata": [{"h_before_resize": 96, "w_before_resize": 288}] * 2,
+                    "depth_orig": [np.where(rng.random((1, 96, 288)) < 0.3, rng.random((1, 96, 288)) * 60 + 2, 0).astype(np.float32) for _ in range(2)]}]
+
+    def cfg_for(out, epochs):
+        cfg = make_cfg(arch, 18)
+        cfg.OUTPUT_DIR = str(out); cfg.LOG_PERIOD = 2; cfg.SOLVER.MAX_EPOCHS = epochs; cfg.SOLVER.LR_STEPS = (1,); cfg.TEST.EVAL_PERIOD = 1
+        return cfg
+
+    sd = OM.init_state_dict(18, with_pose=not sup, seed=33)
+    full = FakeDDP(build(arch, 18, sd))
+    rec = do_train(cfg_for(tmp_path / "full", 2), full, loader, test_loader)
+    files = sorted(f for f in os.listdir(tmp_path / "full"))
+    assert files == ["last_checkpoint", "metrics.json", "model_0000000.pth", "model_0000001.pth", "model_final.pth"]
+    lines = [json.loads(l) for l in open(tmp_path / "full" / "metrics.json")]
+    assert lines == rec and [r["iteration"] for r in rec] == [2, 3, 5, 6]            # LOG_PERIOD 2 of 3 batches + one evaluation record per epoch
+    assert all(np.isfinite(r["total_loss"]) for r in rec if "total_loss" in r)
+    assert "kitti evaluator/abs_rel" in rec[1] and "kitti evaluator (0-30m)/d1" in rec[3]
+    cfg = cfg_for(tmp_path, 2)
+    if sup:
+        want = [(cfg.SOLVER.DEPTH_LR - cfg.SOLVER.DEPTH_END_LR) * (1 - g / 6) ** 0.9 + cfg.SOLVER.DEPTH_END_LR for g in (1, 4)]
+        assert abs(rec[0]["lr"] - want[0]) < 1e-12 and abs(rec[2]["lr"] - want[1]) < 1e-12       # step g runs on f(g - 1)
+    else:
+        assert rec[0]["lr"] == cfg.SOLVER.DEPTH_LR and abs(rec[2]["lr"] - cfg.SOLVER.DEPTH_LR * cfg.SOLVER.GAMMA) < 1e-15   # milestone at epoch 1
+    # a run that died after epoch 0: its directory holds what the uninterrupted run had written by then
+    os.makedirs(tmp_path / "part")
+    shutil.copy(tmp_path / "full" / "model_0000000.pth", tmp_path / "part" / "model_0000000.pth")
+    with open(tmp_path / "part" / "last_checkpoint", "w") as f:
+        f.write("model_0000000.pth")
+    resumed = FakeDDP(build(arch, 18, OM.init_state_dict(18, with_pose=not sup, seed=34)))
+    rec2 = do_train(cfg_for(tmp_path / "part", 2), resumed, loader, None, resume=True)
+    assert [r["iteration"] for r in rec2] == [5] and rec2[0]["lr"] == rec[2]["lr"]
+    for (k, a), (_, b) in zip(full.module.state_dict().items(), resumed.module.state_dict().items()):
         assert torch.equal(a, b), k
