@@ -199,3 +199,50 @@ def test_lr_schedules():
     assert abs(poly_lr(cfg, 0, 100) - 1e-4) < 1e-12 and abs(poly_lr(cfg, 100, 100) - 1e-5) < 1e-12
     assert abs(poly_lr(cfg, 50, 100) - ((1e-4 - 1e-5) * 0.5 ** 0.9 + 1e-5)) < 1e-12
     assert multistep_lr(2e-4, 14, (15,), 0.1) == 2e-4 and abs(multistep_lr(2e-4, 15, (15,), 0.1) - 2e-5) < 1e-12
+
+
+def _worker_aux(rank, world, port, out, tmp):
+    """N > 1 paths of the code around the trainer: evaluator gather, loss-meter average, rank-0-only checkpoint files."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simpledepthestimation_amd.checkpoint import DetectionCheckpointer
+        from simpledepthestimation_amd.config import get_cfg
+        from simpledepthestimation_amd.engine.loops import _LossMeter
+        from simpledepthestimation_amd.evaluation import kitti_evaluator
+        ev = kitti_evaluator(get_cfg(), None)
+        # per-image result rows as sde_depth_metrics would leave them (12 doubles; column 9 = valid-pixel count): rank r holds r + 1 images,
+        # one of them without valid pixels
+        for i in range(rank + 1):
+            row = torch.full((12,), float(10 * rank + i), dtype=torch.float64); row[9] = 5.0
+            ev.metrics.append(row)
+        empty = torch.zeros(12, dtype=torch.float64)
+        ev.metrics.append(empty)
+        res = ev.evaluate()
+        meter = _LossMeter()
+        meter.add({"a_loss": torch.tensor(1.0 + rank), "b_loss": torch.tensor(10.0 * (rank + 1))})
+        meter.add({"a_loss": torch.tensor(3.0 + rank), "b_loss": torch.tensor(10.0 * (rank + 1))})
+        path = DetectionCheckpointer(Tiny(), tmp).save("model_0000000", iteration=0)
+        out[rank] = (res, meter.flush(), path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp2_evaluator_gather_loss_average_and_rank0_checkpoint(tmp_path):
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker_aux, args=(r, 2, port, out, str(tmp_path))) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        (res0, loss0, path0), (res1, loss1, path1) = out[0], out[1]
+    # images: rank 0 -> value 0; rank 1 -> values 10, 11; the two empty images are skipped: mean of (0, 10, 11) on rank 0, {} elsewhere
+    assert res1 == {} and list(res0) == ["kitti evaluator"]
+    assert res0["kitti evaluator"] == {k: 7.0 for k in ("abs_rel", "sq_rel", "rms", "log_rms", "d1", "d2", "d3")}
+    # mean over the two adds per rank, then over ranks (comm.reduce_dict average): a = ((1+3)/2 + (2+4)/2) / 2, b = (10 + 20) / 2
+    assert loss0 == loss1 == {"a_loss": 2.5, "b_loss": 15.0}
+    assert path1 is None and path0 is not None and sorted(os.listdir(tmp_path)) == ["last_checkpoint", "model_0000000.pth"]
