@@ -7,8 +7,10 @@ the nearest-neighbour resize back to the original size (and the crop un-pastes) 
 through, the Garg crop is a window, the optional median scaling and the nine error sums run on the device, and nothing is copied to the host
 until ``evaluate()``.  The four evaluators of a config share the uploaded ground truth and the medians of an image through the ``outputs`` dict.
 
-Not built: ``kitti_depth_saver`` (PNG writing through cv2; I/O, not compute)."""
+``kitti_depth_saver`` writes the restored full-size predictions as 16-bit PNGs with the reference's scaling (``depth * 255`` truncated to uint16,
+utils/file_utils.py:L5-8: the same "/255" convention its loader reads back, loading.py:L59) through Pillow instead of cv2."""
 import logging
+import os
 
 import numpy as np
 import torch
@@ -132,3 +134,44 @@ def _ranged(name, lo, hi, tag):
 kitti_evaluator_0_30 = _ranged("kitti_evaluator_0_30", 1e-3, 30, "kitti evaluator (0-30m)")
 kitti_evaluator_30_50 = _ranged("kitti_evaluator_30_50", 30, 50, "kitti evaluator (30-50m)")
 kitti_evaluator_50_80 = _ranged("kitti_evaluator_50_80", 50, 80, "kitti evaluator (50-80m)")
+
+
+def write_depth(depth, save_path):
+    """utils/file_utils.py:L5-8: uint16 PNG of ``depth * 255`` (truncation, as ``astype(np.uint16)``)."""
+    from PIL import Image
+    scaled = (np.asarray(depth, dtype=np.float32) * 255).astype(np.uint16)
+    Image.fromarray(scaled).save(save_path, format="PNG", compress_level=3)
+
+
+@EVALUATOR_REGISTRY.register()
+class kitti_depth_saver(DatasetEvaluator):
+    """Saves every prediction, restored to the original image size by the same index maps the metric evaluators use (depth_evaluation.py:L163-203),
+    to ``<output_folder>/<date>_<drive>_<img_id>.png``.  The gather through the maps runs on the device; one device -> host copy per image."""
+
+    def __init__(self, cfg, output_folder):
+        super().__init__(cfg)
+        self._logger = logging.getLogger(__name__)
+        self.use_gt_scale = bool(cfg.TEST.GT_SCALE)
+        self.output_folder = output_folder
+        self._maps = {}
+
+    def process(self, inputs, outputs):
+        for i, (pred, meta) in enumerate(zip(outputs["depth_pred"], inputs["metadata"])):
+            pred = pred.detach().squeeze().float()
+            if self.preprocess_chain:
+                rows, cols = backward_maps(tuple(pred.shape), meta, self.preprocess_chain)
+                ry, cx = torch.from_numpy(rows).to(pred.device).long(), torch.from_numpy(cols).to(pred.device).long()
+                full = pred[ry.clamp(min=0)][:, cx.clamp(min=0)] * ((ry >= 0)[:, None] & (cx >= 0)[None, :])
+            else:
+                full = pred
+            if self.use_gt_scale and "depth_gt_orig" in inputs:
+                gt = torch.as_tensor(inputs["depth_gt_orig"][i]).squeeze().to(full.device, torch.float32)
+                valid = (gt > 1e-3) & (gt < 80)
+                full = full * gt[valid].median() / full[valid].median()
+            name = f"{meta['date']}_{meta['drive']}_{meta['img_id']}.png"
+            os.makedirs(self.output_folder, exist_ok=True)
+            write_depth(full.cpu().numpy(), os.path.join(self.output_folder, name))
+
+    def evaluate(self):
+        self._logger.info("depth saved to %s%s", self.output_folder, " w/ gt scale" if self.use_gt_scale else "")
+        return None

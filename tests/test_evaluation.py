@@ -4,6 +4,8 @@ GPU part: sde_depth_metrics through the C ABI and the evaluator classes against 
 
 Tolerances: valid-pixel counts, crop windows, index maps and medians are exact; the nine metrics are float reductions -- the reference reduces in
 float32 (numpy pairwise), the kernel in float64 over float32 terms -- compared at 2e-5 relative (abs_rel's north-star tolerance is 2e-3 absolute)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -177,3 +179,24 @@ def test_inference_on_dataset_runs_the_model_in_eval_mode():
     want = np.mean(np.array(rows, np.float64), axis=0)
     got = res["kitti evaluator"]
     np.testing.assert_allclose([got[n] for n in ("abs_rel", "sq_rel", "rms", "log_rms", "d1", "d2", "d3")], want[2:], rtol=2e-5, atol=1e-7)
+
+
+def test_depth_saver_writes_the_reference_png_format(tmp_path):
+    """CPU tensors suffice here: the saver's restore is an index gather.  16-bit PNG of depth * 255, truncated (file_utils.py:L5-8), named
+    <date>_<drive>_<img_id>.png, restored to the original size through the Resize index maps."""
+    from PIL import Image
+    from simpledepthestimation_amd.config import get_cfg
+    from simpledepthestimation_amd.evaluation import EVALUATOR_REGISTRY
+    rng = np.random.default_rng(0)
+    pred = (rng.random((2, 1, 24, 80)) * 80).astype(np.float32)
+    metas = [{"date": "2011_09_26", "drive": "0002", "img_id": f"{i:010d}", "h_before_resize": 37, "w_before_resize": 124} for i in range(2)]
+    saver = EVALUATOR_REGISTRY.get("kitti_depth_saver")(get_cfg(), str(tmp_path / "out"))
+    saver.process({"metadata": metas}, {"depth_pred": torch.from_numpy(pred)})
+    assert saver.evaluate() is None
+    assert sorted(os.listdir(tmp_path / "out")) == ["2011_09_26_0002_0000000000.png", "2011_09_26_0002_0000000001.png"]
+    for i in range(2):
+        img = Image.open(tmp_path / "out" / f"2011_09_26_0002_{i:010d}.png")
+        got = np.array(img)
+        ymap, xmap = OE.backward_maps((24, 80), metas[i], ["Resize"])
+        want = (pred[i, 0][ymap[:, None], xmap[None, :]] * 255).astype(np.uint16)
+        assert got.dtype == np.uint16 and got.shape == (37, 124) and np.array_equal(got, want)
