@@ -211,6 +211,7 @@ class HipTrainer:
                         torch.cuda.current_stream().wait_stream(st_)
                     self._wreduce.forked = False
                 self._wreduce.jobs, self._wreduce._seen = [], set()       # nothing left registered if backward raised
+                self._wreduce.queue = []
 
     def _backward_rest(self):
         self._backward(self._cut.backward_rest)

@@ -227,8 +227,17 @@ class _Conv2d(torch.autograd.Function):
                     meta = dict(M=M, N=Cout, K=KH * KW * (C0 + C1), k=KH, s=stride, mode=int(upcat), splits=splits,
                                 bytes=esz * (B * H0 * W0 * C0 + B * IH * IW * C1 + M * ldy) + 8 * splits * Cout * KH * KW * (C0 + C1))
                 forked = need_dx and L.SIDE_STREAM and L.PROFILE is None
+                # layers with very large operands (PackNet's full-resolution 64-channel maps: 190 MB each) fork on their own: holding three of
+                # them alive for a group pushes the working set out of the Infinity Cache (PackNet-1A: 60.2 vs 58.4 ms/step when grouped)
+                op_bytes = (dz.numel() + x0.numel() + (x1.numel() if x1 is not None else 0)) * dz.element_size()
+                grouped = forked and L.WGRAD_GROUP > 1 and WGRAD_DEFER is not None and not L.LATE_JOIN and op_bytes <= L.GROUP_MAX_BYTES
+                if forked and not grouped and WGRAD_DEFER is not None:
+                    WGRAD_DEFER.run_queue()              # keep the side stream in layer order
                 cur = torch.cuda.current_stream()
-                if forked:
+                if grouped:
+                    import contextlib
+                    wctx = contextlib.nullcontext()      # the launch happens later, inside WGradReducer.run_queue's side-stream context
+                elif forked:
                     side = L.side_stream()
                     if WGRAD_DEFER is not None:
                         WGRAD_DEFER.join_pending(keep=L.JOIN_LAG - 1)      # lagging joins of earlier layers
@@ -243,6 +252,23 @@ class _Conv2d(torch.autograd.Function):
                 slab_bytes = 4 * splits * Cout * KH * KW * (C0 + C1)
                 defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and slab_bytes <= L.DEFER_MAX_BYTES and WGRAD_DEFER.accepts(wslot)) else None
                 slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
+                if grouped:
+                    side_g = L.side_stream(rotate=False)
+                    if defer is not None:
+                        defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin)
+                        def launch(d=d, slab=slab):
+                            L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits, L.stream()), "sde_conv_wgrad_partial")
+                            slab.record_stream(side_g)
+                    else:
+                        def launch(d=d, slab=slab, dw=dw):
+                            L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw), int(wslot is not None), L.stream()),
+                                    "sde_conv_wgrad")
+                            slab.record_stream(side_g)
+                    WGRAD_DEFER.queue.append((launch, (dz, x0, x1, slab, dw)))
+                    if len(WGRAD_DEFER.queue) >= L.WGRAD_GROUP:
+                        WGRAD_DEFER.run_queue()
+                    st["dw"], st["forked"], st["side"] = (None if wslot is not None else dw), False, None
+                    return
                 with wctx:
                     if defer is not None:
                         _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits, L.stream()),
@@ -331,6 +357,25 @@ class WGradReducer:
         self.jobs, self._seen = [], set()
         self.forked = False        # some GEMM of this phase still runs on the side stream (late join)
         self.pending = []          # (event behind a layer's side-stream work, its operands) of convolutions whose join is lagging (SDE_JOIN_LAG)
+        self.queue = []            # SDE_WGRAD_GROUP > 1: (launch closure, operands) of layers whose weight-gradient GEMM waits for its group's fork
+
+    def run_queue(self):
+        """SDE_WGRAD_GROUP > 1: launch the queued weight-gradient GEMMs of the last few layers behind ONE fork of the side stream (one
+        cross-stream edge per group in the captured graph instead of one per layer) and leave one lagging join for the whole group."""
+        if not self.queue:
+            return
+        side = L.side_stream()
+        self.join_pending(keep=max(0, L.JOIN_LAG - 1))
+        side.wait_stream(torch.cuda.current_stream())
+        refs = []
+        with torch.cuda.stream(side):
+            for launch, operands in self.queue:
+                launch()
+                refs.append(operands)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self.pending.append((ev, refs))
+        self.queue = []
 
     def join_pending(self, keep=0):
         """Make the current stream wait for all but the newest `keep` lagging weight-gradient GEMMs and release their operands."""
@@ -347,6 +392,7 @@ class WGradReducer:
         self.jobs.append((slab, wslot, (src_ptr, wslot.data_ptr(), rows, Cout, KHW, Cin_pad, Cin_real, 1)))
 
     def flush(self):
+        self.run_queue()
         self.join_pending()
         if self.forked:
             for st_ in L.all_side_streams():
