@@ -162,7 +162,17 @@ int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy);
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy);
 /* Tuning / test knob: the LDS-halo 3x3 kernel is used when a launch has at least this many workgroups (default 192; 0 = whenever it
  * applies, negative = never).  Returns the previous value.  Results do not depend on it beyond fp32 summation order. */
-int sde_conv_set_halo_min_blocks(int min_blocks); /* tile the dispatcher picks: BM*1000 + BN (profiling aid) */
+int sde_conv_set_halo_min_blocks(int min_blocks);
+/* Dispatcher options (process-wide; A/B measurements and tests): returns the previous value, negative on a bad key / value.  Results do
+ * not depend on them beyond fp32 summation order.
+ *   SDE_OPT_PGEMM        1 (default): layers with 64-channel-multiple inputs run on the persistent LDS-DMA GEMM (csrc/pgemm.hip); 0: never
+ *   SDE_OPT_PGEMM_DEPTH  stages of its LDS ring: 3 or 4 (default 4)
+ *   SDE_OPT_PGEMM_3X3    1: it also takes the 3x3 stride-1 layers the LDS-halo kernel would get (default 0) */
+#define SDE_OPT_PGEMM 1
+#define SDE_OPT_PGEMM_DEPTH 2
+#define SDE_OPT_PGEMM_3X3 3
+#define SDE_OPT_PGEMM_TILE 4 /* force its tile: 64064, 128064, 128128; 0 (default) = chosen per layer */
+int sde_conv_set_option(int key, int value);
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).
  * slab: caller workspace [splits][Cout][KH*KW*(C0+C1)] fp32, splits = sde_conv_wgrad_splits(d, Cout): one fp32 partial per pixel range,

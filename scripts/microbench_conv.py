@@ -18,7 +18,22 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride, pad, reflect, upcat(C1)
     ("dec_up11_96_32", 12, 48, 160, 32, 32, 3, 1, 1, True, 64),
     ("dec_up01_16_16", 12, 96, 320, 16, 16, 3, 1, 1, True, 0),
     ("stem_7x7", 12, 192, 640, 3, 64, 7, 2, 3, False, 0),
+    ("l2_1x1_128_512", 12, 24, 80, 128, 512, 1, 1, 0, False, 0),
+    ("l2_1x1_512_128", 12, 24, 80, 512, 128, 1, 1, 0, False, 0),
+    ("l3_1x1_256_1024", 12, 12, 40, 256, 1024, 1, 1, 0, False, 0),
+    ("l4_1x1_512_2048", 12, 6, 20, 512, 2048, 1, 1, 0, False, 0),
+    ("l4_1x1_2048_512", 12, 6, 20, 2048, 512, 1, 1, 0, False, 0),
+    ("l2_3x3s2_128_128", 12, 48, 160, 128, 128, 3, 2, 1, False, 0),
+    ("dec_up40_2048_256", 12, 6, 20, 2048, 256, 3, 1, 1, True, 0),
+    ("dec_up41_1280_256", 12, 6, 20, 256, 256, 3, 1, 1, True, 1024),
+    ("dec_up30_256_128", 12, 12, 40, 256, 128, 3, 1, 1, True, 0),
+    ("dec_up20_128_64", 12, 24, 80, 128, 64, 3, 1, 1, True, 0),
+    ("dec_up10_64_32", 12, 48, 160, 64, 32, 3, 1, 1, True, 0),
 ]
+for key, env in ((HN.OPT_PGEMM, "PG"), (HN.OPT_PGEMM_DEPTH, "PGD"), (HN.OPT_PGEMM_3X3, "PG3")):
+    if os.environ.get(env) is not None:
+        HN.set_option(key, int(os.environ[env]))
+print("options:", {e: os.environ.get(e) for e in ("PG", "PGD", "PG3")})
 dt = torch.bfloat16
 dev = "cuda"
 print("lib:", L.LIB_PATH)

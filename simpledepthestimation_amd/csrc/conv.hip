@@ -23,8 +23,10 @@
 
 #include "common.h"
 #include "sde_hip.h"
+#include "conv_common.h"
 
 namespace {
+using namespace sdeconv;
 
 template <int I> using IC = std::integral_constant<int, I>;
 
@@ -36,26 +38,6 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int V = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int V = 8; };
-
-__device__ __forceinline__ int reflect1(int i, int n) {
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * (n - 1) - i;
-    return i;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Shared gather description (forward input side)
-// ------------------------------------------------------------------------------------------------------------------
-struct Gather {
-    const void* x0; const void* x1;
-    int C0, C1, Cin;      // channels (elements) of source 0 / 1 and of the virtual input (C0 + C1)
-    int H0, W0;           // stored spatial size of x0
-    int IH, IW;           // virtual input spatial size
-    int mode;             // SDE_SRC_PLAIN / SDE_SRC_UPCAT / SDE_SRC_ZEROINS
-    int KH, KW, stride, pad, reflect;
-    int Bn, OH, OW, M;    // output pixels M = Bn*OH*OW
-    int Ktot;             // KH*KW*Cin
-};
 
 template <typename T>
 __device__ __forceinline__ uint4 gather16(const Gather& g, int n, int ih, int iw, int ci) {
@@ -73,15 +55,6 @@ __device__ __forceinline__ uint4 gather16(const Gather& g, int n, int ih, int iw
         src = (const T*)g.x0 + ((size_t)(n * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1)) * g.C0 + ci;
     }
     return *reinterpret_cast<const uint4*>(src);
-}
-
-// XCD-aware work order (8 XCDs, each with a private L2; workgroups are dealt round-robin over the XCDs): remap the linear
-// block id so that every XCD walks one CONTIGUOUS range of logical tiles.  Neighbouring tiles share halo rows, filter taps and
-// the A rows of all N tiles, so those re-reads become hits in that XCD's L2 instead of refills from beyond it.  Bijective
-// for any grid size; placement only affects speed, never results.
-__device__ __forceinline__ int xcd_remap(int bid, int nb) {
-    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -110,18 +83,6 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 // ------------------------------------------------------------------------------------------------------------------
 // Forward / data-gradient implicit GEMM:  Y[M, Cout] = im2col(X)[M, K] * Wp[Cout, K]^T
 // ------------------------------------------------------------------------------------------------------------------
-struct IGemmP {
-    Gather g;
-    const void* w;        // packed [Cout][Ktot]
-    const float* bias;    // [Cout] or null
-    void* y;              // [M][ldy]
-    float* stats;         // [tiles_m][Cout][2] or null
-    int Cout, ldy, act;
-    int ksplit;           // > 1: the K loop is cut into ksplit ranges, each workgroup writes its raw fp32 tile to ws[split][M][ldy]
-    float* ws;            //      and splitk_finish_kernel sums them in a fixed order and applies bias / activation / statistics
-    int no_kfull;         // experiment switch (SDE_NO_KFULL): disable the scalar-offset 1x1 loader
-};
-
 constexpr int KSTAGE_BYTES = 128;   // K bytes per row per pipeline stage (2 MFMA sub-blocks of 64 B)
 constexpr int NTHREADS = 256;
 
@@ -139,25 +100,6 @@ __device__ __forceinline__ const T* gather_ptr(const Gather& g, int n, int ih, i
     return (const T*)g.x0 + ((size_t)((n * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1))) * g.C0 + ci;
 }
 
-// ---- branch-free gather: byte offsets for hardware-bounds-checked buffer loads (an out-of-range offset reads zeros), so
-// padding, inserted zeros and ragged tiles cost no control flow and the compiler can keep several stages of loads in flight.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-constexpr unsigned kOOB = 0x80000000u;      // every tensor is < 2 GiB, so this offset is always out of range
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, long bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
-}
-// voffset per lane + a wave-uniform scalar offset (the K position of the pipeline stage): no per-load VALU address arithmetic
-__device__ __forceinline__ uint4 buf_load16s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-
-// Source kinds.  bf16 kernels are specialised on the kind (straight-line loop bodies: with the kind decided at run time the
-// loop breaks into ~70 basic blocks per 32 MFMAs and nothing overlaps); SRC_RUNTIME keeps one generic fp32 instantiation.
-constexpr int SRC_RUNTIME = -1, SRC_PLAIN_ZERO = 0, SRC_PLAIN_REFLECT = 1, SRC_UPCAT_REFLECT = 2, SRC_ZEROINS_ZERO = 3, SRC_1X1 = 4;
 
 template <int SRC> __device__ __forceinline__ int src_mode(const Gather& g) {
     if (SRC == SRC_RUNTIME) return g.mode;
@@ -1346,13 +1288,32 @@ int fill_gather(const sde_conv_desc* d, Gather& g, const char* who) {
 
 }  // namespace
 
+// persistent LDS-DMA GEMM (pgemm.hip)
+namespace sdeconv {
+bool pgemm_applicable(const Gather& g, int dtype, int ldy);
+int pgemm_tile(long M, int ldy);
+int pgemm_run(const IGemmP& p, int depth, hipStream_t s);
+extern int g_pgemm_force_tile;
+}
+namespace {
+int g_use_pgemm = 1;        // sde_conv_set_option(SDE_OPT_PGEMM, 0/1)
+int g_pgemm_depth = 4;      // sde_conv_set_option(SDE_OPT_PGEMM_DEPTH, 3/4): ring stages
+int g_pgemm_3x3 = 0;        // sde_conv_set_option(SDE_OPT_PGEMM_3X3, 1): also take the layers the LDS-halo 3x3 kernel would get
+bool use_pgemm(const Gather& g, int dtype, int ldy) {
+    if (!g_use_pgemm || !pgemm_applicable(g, dtype, ldy)) return false;
+    return g_pgemm_3x3 || !use_halo(g, dtype, ldy);
+}
+}
+
 extern "C" {
 
 // Split-K factor of a forward / data-gradient GEMM: layers whose 64x64 tiling leaves most of the 256 CUs x 4 workgroup slots empty while
 // the K loop is long (layer4 and the first decoder levels: M = 1440 ... 5760 pixels) cut K into up to 8 ranges.
 static int pick_ksplit(const Gather& g, int dtype, int ldy) {
     static const int off = [] { const char* e = getenv("SDE_NO_SPLITK"); return e ? atoi(e) : 0; }();
-    if (off || use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064 || ldy % 4) return 1;
+    const bool pg = use_pgemm(g, dtype, ldy);
+    if (pg && pgemm_tile(g.M, ldy) != 64064) return 1;
+    if (off || (!pg && use_halo(g, dtype, ldy)) || pick_tile(g.M, ldy, g.Ktot) != 64064 || ldy % 4) return 1;
     const long tiles = (long)sde_cdiv(g.M, 64) * sde_cdiv(ldy, 64);
     const int nk = sde_cdiv(g.Ktot, dtype == SDE_BF16 ? 64 : 32);
     static const long tmax = [] { const char* e = getenv("SDE_SPLITK_TILES"); return e ? atol(e) : 384L; }();      // split when fewer tiles than this ...
@@ -1381,7 +1342,10 @@ static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const flo
         SDE_CHECK_ARG(ws_bytes >= (size_t)S * p.g.M * ldy * sizeof(float), "sde_conv_fwd_ws: workspace too small (%zu bytes)", ws_bytes);
         p.ksplit = S; p.ws = ws;
     }
-    if (use_halo(p.g, d->dtype, ldy)) dispatch_halo(p, (hipStream_t)stream);
+    if (use_pgemm(p.g, d->dtype, ldy)) {
+        SDE_CHECK_ARG((p.ksplit - 1) * sde_cdiv(p.g.Ktot / 64, p.ksplit) < p.g.Ktot / 64, "sde_conv_fwd: empty K split");
+        sdeconv::pgemm_run(p, g_pgemm_depth, (hipStream_t)stream);
+    } else if (use_halo(p.g, d->dtype, ldy)) dispatch_halo(p, (hipStream_t)stream);
     else if (d->dtype == SDE_BF16) dispatch_igemm<bf16_t>(p, (hipStream_t)stream);
     else dispatch_igemm<float>(p, (hipStream_t)stream);
     SDE_CHECK_LAUNCH("sde_conv_fwd");
@@ -1415,6 +1379,7 @@ static int gather_of(const sde_conv_desc* d, Gather& g) { return fill_gather(d, 
 
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
     Gather g;
+    if (gather_of(d, g) == SDE_OK && use_pgemm(g, d->dtype, ldy)) return 7000000 + pgemm_tile(g.M, ldy);   // 7<BM><BN>: persistent LDS-DMA GEMM
     if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return 3128000 + halo_bn(g, ldy);      // 3128<BN>: LDS-halo 3x3 kernel
     return pick_tile((long)d->Bn * d->OH * d->OW, ldy, d->KH * d->KW * (d->C0 + d->C1));
 }
@@ -1422,6 +1387,7 @@ int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
     // number of M tiles the dispatcher will use (= rows of the BN-statistics slab)
     Gather g;
+    if (gather_of(d, g) == SDE_OK && use_pgemm(g, d->dtype, ldy)) return sde_cdiv(g.M, pgemm_tile(g.M, ldy) / 1000);
     if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return halo_tiles_m(g);
     const long M = (long)d->Bn * d->OH * d->OW;
     return sde_cdiv(M, pick_tile(M, ldy, d->KH * d->KW * (d->C0 + d->C1)) / 1000);
@@ -1542,6 +1508,16 @@ int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int
     }
     SDE_CHECK_LAUNCH("sde_pack_weight");
     return SDE_OK;
+}
+
+int sde_conv_set_option(int key, int value) {
+    int* slot = key == SDE_OPT_PGEMM ? &g_use_pgemm : key == SDE_OPT_PGEMM_DEPTH ? &g_pgemm_depth : key == SDE_OPT_PGEMM_3X3 ? &g_pgemm_3x3 : key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : nullptr;
+    SDE_CHECK_ARG(slot, "sde_conv_set_option: unknown key %d", key);
+    SDE_CHECK_ARG(key != SDE_OPT_PGEMM_DEPTH || value == 3 || value == 4, "sde_conv_set_option: ring depth must be 3 or 4");
+    SDE_CHECK_ARG(key != SDE_OPT_PGEMM_TILE || value == 0 || value == 64064 || value == 128064 || value == 128128, "sde_conv_set_option: bad tile %d", value);
+    const int old = *slot;
+    *slot = value;
+    return old;
 }
 
 int sde_conv_set_halo_min_blocks(int min_blocks) {

@@ -1,0 +1,423 @@
+// Persistent implicit-GEMM convolution for gfx950 (bf16 storage, fp32 accumulate): the forward / data-gradient GEMM of every layer whose
+// input channel count is a multiple of 64 (all of ResNet-18/50 but the stem, the DepthDecoder down to 64 channels).
+//
+//   Y[M, Cout] = im2col(X)[M, K] * Wp[Cout, K]^T,   M = B*OH*OW pixels,  K = KH*KW*Cin
+//
+// Replaces the same reference calls as conv.hip (nn.Conv2d / ReflectionPad2d / F.interpolate / torch.cat of
+// detectron2/layers/resnet_encoder.py:L88-99 and detectron2/layers/depth_decoder.py:L21-53,L95-110, and their autograd backward).
+//
+// Why a second main loop (profiles/README.md, round 1): the register-staged 64x64 kernel spends ~110 address / staging instructions
+// per 8 MFMAs and drains its pipeline at every tile; the layers of this network are 25-40 us GEMMs with 1-36 K stages, so a launch is
+// mostly prologue and epilogue latency.  This kernel is built the other way round:
+//   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write, the XOR swizzle is applied
+//     on the per-lane SOURCE address (the LDS image of a DMA piece is lane-linear), padding / ragged rows are out-of-range buffer
+//     offsets (the DMA then writes zeros);
+//   * a ring of D stages per workgroup with D-1 stages of DMA always in flight behind a counted s_waitcnt vmcnt(N) and ONE raw
+//     s_barrier per stage;
+//   * workgroups are PERSISTENT: each walks a strided list of (tile, K-range) work items and the ring runs on across items, so the first
+//     stages of the next tile are already landing while the current tile is multiplied and written out (short-K 1x1 layers never see
+//     an empty pipeline);
+//   * v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the row operand: a lane then holds 4 consecutive output channels of ONE pixel per
+//     accumulator group, i.e. 8-byte NHWC pieces, staged through the just-consumed ring slot for 16-byte coalesced stores and the
+//     per-tile BatchNorm (sum, sum^2) partials;
+//   * no VGPR-destination global load anywhere (the bias comes in by DMA with a tile's first stage and initialises the accumulators),
+//     so the compiler never has a reason to drain vmcnt.
+#include "conv_common.h"
+
+namespace sdeconv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 pg_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float pg_f32x16;
+typedef __attribute__((address_space(3))) void pg_lds_void;
+
+constexpr int PG_THREADS = 256;
+constexpr int PG_STAGE_K_BYTES = 128;      // 64 bf16 of K per stage
+
+template <int N> __device__ __forceinline__ void pg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void pg_dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pg_lds_void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void pg_dma4(__amdgpu_buffer_rsrc_t r, unsigned char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pg_lds_void*)lds, 4, voff, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pg_pack_bf16x2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// LDS stores go through inline asm: hipcc orders every LDS store it can see behind ALL LDS-DMA still in flight (s_waitcnt vmcnt(0)), which
+// would drain the ring at every epilogue.  These stores only touch the slot that was just consumed; the caller waits lgkmcnt(0) itself.
+typedef __attribute__((ext_vector_type(2))) unsigned pg_u32x2;
+__device__ __forceinline__ unsigned pg_lds_addr(const void* p) { return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void pg_lds_store8(unsigned addr, unsigned a, unsigned b) {
+    pg_u32x2 v = {a, b};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+struct PGemmP {
+    IGemmP p;
+    int tiles_n, tiles_mn, total;       // work items = tiles_mn * ksplit, N tiles of one M tile adjacent
+    int nk_total, nk_per;               // K stages of the whole GEMM / per split
+};
+
+// One work item: tile (tile_m, tile_n), K stages [s_begin, s_begin + nk)
+struct PGWork {
+    int tile_m, tile_n, split, s_begin, nk;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ PGWork pg_work(const PGemmP& q, int w) {
+    PGWork r;
+    const int logical = xcd_remap(w, q.total);
+    r.split = logical / q.tiles_mn;
+    const int rem = logical - r.split * q.tiles_mn;
+    r.tile_m = rem / q.tiles_n;
+    r.tile_n = rem - r.tile_m * q.tiles_n;
+    r.s_begin = r.split * q.nk_per;
+    const int e = r.s_begin + q.nk_per;
+    r.nk = (e < q.nk_total ? e : q.nk_total) - r.s_begin;
+    if (r.nk < 0) r.nk = 0;
+    return r;
+}
+
+template <int BM, int BN, int SRC, int D>
+__global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;          // 2 x 2 waves
+    constexpr int FM = WTM / 32, FN = WTN / 32;        // 32x32 fragments per wave: pixels (MFMA columns) x channels (MFMA rows)
+    constexpr int XP = BM / 32, WP = BN / 32;          // DMA pieces (8 rows x 128 B) per wave per stage
+    constexpr int L = XP + WP;                         // DMA instructions per wave per stage
+    constexpr int STAGE_BYTES = (BM + BN) * PG_STAGE_K_BYTES;
+    constexpr int BIAS_BYTES = BN * 4;
+    constexpr int SLOT_BYTES = STAGE_BYTES;
+    constexpr int BIAS_BASE = D * STAGE_BYTES;          // bias ring [D][BN] floats behind the stage ring, indexed by the workgroup's item count
+    constexpr int EN = BN > 64 ? 64 : BN, NCH = BN / EN;   // the epilogue stages EN output channels at a time
+    constexpr int CST = EN * 2 + 16;                   // staging-tile row stride (bytes): 16-byte aligned, conflict-free 8-byte column writes
+    static_assert(BM * CST + PG_THREADS * 8 <= STAGE_BYTES, "the output staging tile must fit into one ring slot");
+    static_assert(D >= 3 && (D - 2) * L <= 60, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [D][X: BM rows | W: BN rows], [D][BN] bias
+
+    const IGemmP& p = q.p;
+    const Gather& g = p.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int grid = gridDim.x;
+
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(g.x0, (long)g.Bn * g.H0 * g.W0 * g.C0 * 2L);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(g.x1 ? g.x1 : g.x0, g.x1 ? (long)g.Bn * g.IH * g.IW * g.C1 * 2L : 0);
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.w, (long)p.ldy * g.Ktot * 2L);          // packed operand has ldy (padded Cout) rows
+    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(p.bias ? (const void*)p.bias : p.w, p.bias ? (long)p.Cout * 4L : 0);
+    const bool has_bias = p.bias != nullptr && p.ksplit == 1;
+
+    // ---- DMA side: this lane fills 16-byte slot (lane & 7) of rows (lane >> 3) + 8 i of its wave's pieces.  The LDS image of a
+    // piece is lane-linear, so the XOR swizzle of the 16-byte chunk index is applied to the SOURCE: chunk = slot ^ ((row >> 1) & 7).
+    const int drow = lane >> 3, dslot = lane & 7;
+    // ---- load cursor (runs D-1 stages ahead of the compute cursor, across work items)
+    int lw = blockIdx.x;                 // work item being loaded
+    PGWork lwk = pg_work<BM, BN>(q, lw < q.total ? lw : 0);
+    if (lw >= q.total) lwk.nk = 0;
+    int ls = 0;                          // next stage of that item
+    int l_item = 0;                      // items started by the load cursor (bias ring slot = l_item % D)
+    int l_kh = 0, l_kw = 0, l_cb = 0;    // filter tap and channel offset of that stage (wave-uniform)
+    unsigned xbase[XP];                  // per row: byte offset of the pixel (tap (0,0), channel 0) + this lane's swizzled chunk, or kOOB
+    int xih[XP], xiw[XP], xnb[XP];       // per row: input coordinate of tap (0,0) and image index (gather kinds with taps)
+    unsigned woff[WP];                   // per weight row: byte offset of row + swizzled chunk, or kOOB
+
+    auto setup_item = [&]() {            // per-lane addressing state of work item `lwk`
+        const int m0 = lwk.tile_m * BM, n0 = lwk.tile_n * BN;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int row = wave * (BM / 4) + i * 8 + drow;
+            const int chunk = dslot ^ ((row >> 1) & 7);
+            const int m = m0 + row;
+            const bool ok = m < g.M;
+            const int mm = ok ? m : 0;
+            const int n = mm / (g.OH * g.OW);
+            const int rem = mm - n * (g.OH * g.OW);
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+            xih[i] = ih0; xiw[i] = iw0; xnb[i] = ok ? n : -1;
+            if (SRC == SRC_1X1 || SRC == SRC_PLAIN_ZERO)
+                xbase[i] = ok ? (unsigned)(((n * g.H0 + ih0) * g.W0 + iw0) * g.C0 * 2 + chunk * 16) : kOOB;      // may wrap for border pixels: only used when the tap is in range
+            else
+                xbase[i] = (unsigned)(chunk * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            const int row = wave * (BN / 4) + i * 8 + drow;
+            const int chunk = dslot ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            woff[i] = n < p.ldy ? (unsigned)(n * g.Ktot * 2 + chunk * 16) : kOOB;
+        }
+        if (SRC != SRC_1X1) {
+            const int k = lwk.s_begin * 64;
+            const int tap = k / g.Cin;
+            l_cb = k - tap * g.Cin; l_kh = tap / g.KW; l_kw = tap - l_kh * g.KW;
+        }
+    };
+    if (lwk.nk > 0) setup_item();
+
+    int issued = 0;                      // stages issued so far (ring slot = issued % D)
+    auto issue_next = [&]() {
+        if (lwk.nk == 0) return;         // no work left: nothing to issue (uniform)
+        unsigned char* slot = smem + (issued % D) * SLOT_BYTES;
+        unsigned char* sX = slot + (wave * (BM / 4)) * PG_STAGE_K_BYTES;
+        unsigned char* sW = slot + BM * PG_STAGE_K_BYTES + (wave * (BN / 4)) * PG_STAGE_K_BYTES;
+        const unsigned soff = (unsigned)(lwk.s_begin + ls) * (unsigned)PG_STAGE_K_BYTES;
+#pragma unroll
+        for (int i = 0; i < WP; ++i) pg_dma16(rsw, sW + i * 1024, woff[i], soff);
+        if (SRC == SRC_1X1) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) pg_dma16(rs0, sX + i * 1024, xbase[i], soff);
+        } else if (SRC == SRC_PLAIN_ZERO) {
+            const unsigned toff = (unsigned)(((l_kh * g.W0 + l_kw) * g.C0 + l_cb) * 2);
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const bool ok = (xnb[i] >= 0) & ((unsigned)(xih[i] + l_kh) < (unsigned)g.IH) & ((unsigned)(xiw[i] + l_kw) < (unsigned)g.IW);
+                pg_dma16(rs0, sX + i * 1024, ok ? xbase[i] + toff : kOOB, 0);
+            }
+        } else if (SRC == SRC_PLAIN_REFLECT) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int ih = reflect1(xih[i] + l_kh, g.IH), iw = reflect1(xiw[i] + l_kw, g.IW);
+                const unsigned o = (unsigned)((((xnb[i] * g.H0 + ih) * g.W0 + iw) * g.C0 + l_cb) * 2) + xbase[i];
+                pg_dma16(rs0, sX + i * 1024, xnb[i] >= 0 ? o : kOOB, 0);
+            }
+        } else {        // SRC_UPCAT_REFLECT: channels [0, C0) from x0 at half resolution, [C0, Cin) from the skip tensor x1
+            const bool first = l_cb < g.C0;       // wave-uniform (C0 % 64 == 0)
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int ih = reflect1(xih[i] + l_kh, g.IH), iw = reflect1(xiw[i] + l_kw, g.IW);
+                const unsigned o0 = (unsigned)((((xnb[i] * g.H0 + (ih >> 1)) * g.W0 + (iw >> 1)) * g.C0 + l_cb) * 2) + xbase[i];
+                const unsigned o1 = (unsigned)((((xnb[i] * g.IH + ih) * g.IW + iw) * g.C1 + (l_cb - g.C0)) * 2) + xbase[i];
+                if (first) pg_dma16(rs0, sX + i * 1024, xnb[i] >= 0 ? o0 : kOOB, 0);
+                else pg_dma16(rs1, sX + i * 1024, xnb[i] >= 0 ? o1 : kOOB, 0);
+            }
+        }
+        if (ls == 0 && has_bias && wave < BN / 64)        // the item's bias row rides with its first stage (4 B per lane, 64 channels per wave)
+            pg_dma4(rsb, smem + BIAS_BASE + (l_item % D) * BIAS_BYTES + wave * 256, (unsigned)((lwk.tile_n * BN + wave * 64 + lane) * 4));
+        ++issued;
+        if (SRC != SRC_1X1) {
+            l_cb += 64;
+            if (l_cb == g.Cin) { l_cb = 0; if (++l_kw == g.KW) { l_kw = 0; ++l_kh; } }
+        }
+        if (++ls == lwk.nk) {            // next work item of this workgroup
+            ls = 0;
+            ++l_item;
+            lw += grid;
+            if (lw < q.total) { lwk = pg_work<BM, BN>(q, lw); if (lwk.nk > 0) setup_item(); }
+            else lwk.nk = 0;
+        }
+    };
+
+    // ---- compute side
+    const int swz = (lane >> 1) & 7;
+    unsigned koff[4];                    // byte offset of this lane's 16-byte chunk inside its 128-byte row, per 16-deep K step
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = (unsigned)(((2 * kk + lh) ^ swz) << 4);
+    const unsigned xrow0 = (unsigned)((wm * WTM + l31) * PG_STAGE_K_BYTES);
+    const unsigned wrow0 = (unsigned)((BM + wn * WTN + l31) * PG_STAGE_K_BYTES);
+
+    pg_f32x16 acc[FN][FM];
+    int consumed = 0, c_item = 0;        // stages consumed / items finished by the compute side
+
+#pragma unroll 1
+    for (int i = 0; i < D - 1; ++i) issue_next();
+
+#pragma unroll 1
+    for (int cw = blockIdx.x; cw < q.total; cw += grid) {
+        const PGWork wk = pg_work<BM, BN>(q, cw);
+        if (wk.nk == 0) continue;        // (cannot happen with the host's split arithmetic; the load cursor skips such items the same way)
+        const int m0 = wk.tile_m * BM, n0 = wk.tile_n * BN;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+#pragma unroll 1
+        for (int s = 0; s < wk.nk; ++s) {
+            // stage `consumed` must have landed: everything this wave issued for it is older than the newest (D-2) stages
+            if (issued - consumed - 1 >= D - 2) pg_wait_vmcnt<(D - 2) * L>(); else pg_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // every wave's share has landed, and every wave is done with stage consumed-1
+            issue_next();                          // refill the slot of stage consumed-1
+            const unsigned char* slot = smem + (consumed % D) * SLOT_BYTES;
+            pg_bf16x8 wf[4][FN], xf[4][FM];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) wf[kk][j] = *reinterpret_cast<const pg_bf16x8*>(slot + wrow0 + j * 32 * PG_STAGE_K_BYTES + koff[kk]);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) xf[kk][i] = *reinterpret_cast<const pg_bf16x8*>(slot + xrow0 + i * 32 * PG_STAGE_K_BYTES + koff[kk]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], xf[kk][i], acc[j][i], 0, 0, 0);
+            ++consumed;
+        }
+
+        // ---- epilogue.  Lane (pixel l31, half lh) holds channels 8g + 4 lh + {0..3} of each 32-channel fragment.
+        if (p.ksplit > 1) {          // raw fp32 partial tile -> ws[split][m][n]; splitk_finish_kernel applies bias / activation / statistics
+            float* wsp = p.ws + (size_t)wk.split * g.M * p.ldy;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = m0 + wm * WTM + i * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int n = n0 + wn * WTN + j * 32 + 8 * gq + 4 * lh;
+                        if (m < g.M && n < p.ldy)
+                            *reinterpret_cast<float4*>(wsp + (size_t)m * p.ldy + n) =
+                                make_float4(acc[j][i][4 * gq], acc[j][i][4 * gq + 1], acc[j][i][4 * gq + 2], acc[j][i][4 * gq + 3]);
+                    }
+            }
+            ++c_item;
+            continue;
+        }
+        unsigned char* sC = smem + ((consumed - 1) % D) * SLOT_BYTES;       // the slot just consumed: its refill is issued after the next barrier
+        const unsigned sC_a = pg_lds_addr(sC);
+        const float* sbias = reinterpret_cast<const float*>(smem + BIAS_BASE + (c_item % D) * BIAS_BYTES);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {                                 // 64 output channels at a time through the staging tile
+            __builtin_amdgcn_s_barrier();                                  // every wave is done reading the slot / the previous chunk
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if ((wn * WTN + j * 32) / EN != ch) continue;              // wave-uniform
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * WTM + i * 32 + l31;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int nt = wn * WTN + j * 32 + 8 * gq + 4 * lh;    // channel inside the tile
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = acc[j][i][4 * gq + e];
+                            if (has_bias) t += sbias[nt + e];
+                            if (p.act == SDE_ACT_ELU) t = t > 0.f ? t : expm1f(t);
+                            if (n0 + nt + e >= p.Cout) t = 0.f;       // padded output channels are exact zeros
+                            v[e] = t;
+                        }
+                        pg_lds_store8(sC_a + row * CST + (nt - ch * EN) * 2, pg_pack_bf16x2(v[0], v[1]), pg_pack_bf16x2(v[2], v[3]));
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // NOTE: LDS is read through ext_vector types only.  A load typed as a HIP struct vector (uint4, float4 ...) carries struct TBAA info,
+            // which makes hipcc's waitcnt pass alias-check it against the LDS-DMA writes in flight and emit s_waitcnt vmcnt(0) in front of it.
+            constexpr int G8 = EN / 8;                                      // 16-byte groups per staged row
+            const int nc0 = n0 + ch * EN;
+#pragma unroll
+            for (int id = tid; id < BM * G8; id += PG_THREADS) {
+                const int row = id / G8, c8 = id - row * G8;
+                const int m = m0 + row, n = nc0 + c8 * 8;
+                if (m < g.M && n < p.ldy)                                   // ldy % 8 == 0
+                    *reinterpret_cast<u32x4*>((unsigned char*)p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const u32x4*>(sC + row * CST + c8 * 16);
+            }
+            if (p.stats) {
+                // per-tile column sums of y and y^2 (of the rounded values) over the valid rows: PARTS interleaved row sets per column
+                constexpr int PARTS = PG_THREADS / EN;
+                float* red = reinterpret_cast<float*>(sC + BM * CST);       // [PARTS][EN][2]
+                const int c = tid % EN, part = tid / EN;
+                const int rows = (g.M - m0) < BM ? (g.M - m0) : BM;
+                float s1 = 0.f, s2 = 0.f;
+                for (int r = part; r < rows; r += PARTS) {
+                    const float t = (float)*reinterpret_cast<const __bf16*>(sC + r * CST + c * 2);
+                    s1 += t; s2 += t * t;
+                }
+                pg_lds_store8(sC_a + BM * CST + (part * EN + c) * 8, __builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (tid < EN && nc0 + tid < p.Cout) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int z = 0; z < PARTS; ++z) { a += red[(z * EN + tid) * 2]; b += red[(z * EN + tid) * 2 + 1]; }
+                    p.stats[((size_t)wk.tile_m * p.Cout + nc0 + tid) * 2 + 0] = a;
+                    p.stats[((size_t)wk.tile_m * p.Cout + nc0 + tid) * 2 + 1] = b;
+                }
+            }
+        }
+        ++c_item;
+        // the next stage's barrier orders these LDS reads before the slot's refill
+    }
+    pg_wait_vmcnt<0>();      // nothing may be in flight into LDS when the workgroup ends
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int SRC, int D>
+static int pg_launch(const PGemmP& q, hipStream_t s) {
+    constexpr int lds = D * ((BM + BN) * PG_STAGE_K_BYTES + BN * 4);      // stage ring + bias ring
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm_kernel<BM, BN, SRC, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const int per_cu = (160 * 1024) / lds;
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if (grid > q.total) grid = q.total;
+    hipLaunchKernelGGL((pgemm_kernel<BM, BN, SRC, D>), dim3(grid), dim3(PG_THREADS), lds, s, q);
+    return 0;
+}
+
+template <int BM, int BN, int D>
+static int pg_dispatch_src(const PGemmP& q, int src, hipStream_t s) {
+    switch (src) {
+        case SRC_1X1: return pg_launch<BM, BN, SRC_1X1, D>(q, s);
+        case SRC_PLAIN_ZERO: return pg_launch<BM, BN, SRC_PLAIN_ZERO, D>(q, s);
+        case SRC_PLAIN_REFLECT: return pg_launch<BM, BN, SRC_PLAIN_REFLECT, D>(q, s);
+        default: return pg_launch<BM, BN, SRC_UPCAT_REFLECT, D>(q, s);
+    }
+}
+
+// The layers this kernel takes: bf16, every source a multiple of 64 channels (a stage is one filter tap x 64 channels), no zero insertion.
+bool pgemm_applicable(const Gather& g, int dtype, int ldy) {
+    if (dtype != SDE_BF16 || g.mode == SDE_SRC_ZEROINS) return false;
+    if (g.Cin % 64 || g.C0 % 64 || (g.mode == SDE_SRC_UPCAT && !g.reflect)) return false;
+    if (ldy % 8) return false;
+    if ((long)g.Bn * g.IH * g.IW * (g.C0 > g.C1 ? g.C0 : g.C1) * 2L >= 0x7fffffffL) return false;      // 32-bit byte offsets
+    return true;
+}
+
+int pgemm_src_kind(const Gather& g) {
+    if (g.mode == SDE_SRC_UPCAT) return SRC_UPCAT_REFLECT;
+    if (g.KH == 1 && g.KW == 1 && g.pad == 0 && !g.reflect) return SRC_1X1;
+    return g.reflect ? SRC_PLAIN_REFLECT : SRC_PLAIN_ZERO;
+}
+
+// Tile choice (one place): BM*1000 + BN.  128-pixel tiles once they still give two work items per CU.
+int g_pgemm_force_tile = 0;     // sde_conv_set_option(SDE_OPT_PGEMM_TILE, 64064 | 128064 | 128128 | 0 = automatic)
+int pgemm_tile(long M, int ldy) {
+    if (g_pgemm_force_tile) return g_pgemm_force_tile;
+    if (ldy > 64 && (long)sde_cdiv(M, 128) * sde_cdiv(ldy, 128) >= 512) return 128128;
+    if ((long)sde_cdiv(M, 128) * sde_cdiv(ldy, 64) >= 512) return 128064;
+    return 64064;
+}
+
+int pgemm_run(const IGemmP& p, int depth, hipStream_t s) {
+    PGemmP q;
+    q.p = p;
+    const int tile = pgemm_tile(p.g.M, p.ldy);
+    const int BM = tile / 1000, BN = tile % 1000;
+    q.tiles_n = sde_cdiv(p.ldy, BN);
+    q.tiles_mn = sde_cdiv(p.g.M, BM) * q.tiles_n;
+    q.total = q.tiles_mn * p.ksplit;
+    q.nk_total = p.g.Ktot / 64;
+    q.nk_per = sde_cdiv(q.nk_total, p.ksplit);
+    const int src = pgemm_src_kind(p.g);
+    if (tile == 128128) return pg_dispatch_src<128, 128, 3>(q, src, s);
+    if (tile == 128064) return depth == 3 ? pg_dispatch_src<128, 64, 3>(q, src, s) : pg_dispatch_src<128, 64, 4>(q, src, s);
+    return depth == 3 ? pg_dispatch_src<64, 64, 3>(q, src, s) : pg_dispatch_src<64, 64, 4>(q, src, s);
+}
+
+}  // namespace sdeconv

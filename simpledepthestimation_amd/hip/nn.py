@@ -33,6 +33,7 @@ L.register_protos({
     "sde_conv_fwd_ws": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P, ctypes.c_size_t, _P], c_int),
     "sde_conv_fwd_variant": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_set_halo_min_blocks": ([_I], c_int),
+    "sde_conv_set_option": ([_I, _I], c_int),
     "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_wgrad": ([POINTER(ConvDesc), _P, _I, _I, _I, _P, _I, _P, _I, _P], c_int),
     "sde_conv_wgrad_partial": ([POINTER(ConvDesc), _P, _I, _I, _P, _I, _P], c_int),
@@ -57,6 +58,17 @@ L.register_protos({
     "sde_conv3d_wgrad": ([_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], c_int),
     "sde_adam_step": ([_P, _P, _P, _P, _LG, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _I, _P], c_int),
 })
+
+
+OPT_PGEMM, OPT_PGEMM_DEPTH, OPT_PGEMM_3X3, OPT_PGEMM_TILE = 1, 2, 3, 4      # SDE_OPT_* of include/sde_hip.h
+
+
+def set_option(key, value):
+    """sde_conv_set_option: returns the previous value."""
+    old = L.lib().sde_conv_set_option(int(key), int(value))
+    if old < 0:
+        raise L.SdeHipError(f"sde_conv_set_option({key}, {value}) failed: {L.lib().sde_last_error().decode()}")
+    return old
 
 
 def dtype_code(dt):
