@@ -3,6 +3,7 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...        (no launcher: the parent starts the N ranks itself, as detectron2/engine/launch.py:L24-92 does)
 
 Workload (N=1 and per rank for N>1): BASELINE.json configs[1] -- Supervised ResNet-50, bf16 storage / fp32 accumulate,
 bs=12, 192x640, synthetic KITTI-shaped batches, random-init weights.  One "step" = zero-grad + forward +
@@ -17,6 +18,7 @@ Extra objects on that line (tier contract):
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -39,30 +41,21 @@ WORKLOADS = {
 
 
 def synth_batch(arch, B, H, W, seed, device):
-    g = torch.Generator().manual_seed(seed)
-    if arch == "SupDepthModel":
-        img = torch.rand(B, 3, H, W, generator=g)
-        m = torch.rand(B, 1, H, W, generator=g) < 0.3
-        depth = torch.where(m, torch.rand(B, 1, H, W, generator=g) * 79 + 1, torch.zeros(1))
-        batch = {"img": img, "depth": depth}
-    else:
-        from oracle.gen_golden import kitti_K, smooth_images       # input synthesis only (shared with the tests)
-        a, b, c = smooth_images(g, B, H, W)
-        batch = {"img": a, "img_orig": a.clone(), "ctx_img": [b, c], "ctx_img_orig": [b.clone(), c.clone()], "intrinsics": kitti_K(B, H, W)}
+    from simpledepthestimation_amd.data.synthetic import mono_batch, sup_batch
+    batch = sup_batch(B, H, W, seed) if arch == "SupDepthModel" else mono_batch(B, H, W, seed)
     return {k: ([x.to(device) for x in v] if isinstance(v, list) else v.to(device)) for k, v in batch.items()}
 
 
 def build(args, device):
-    from simpledepthestimation_amd.config import get_cfg
+    from simpledepthestimation_amd.config import get_project_cfg
     from simpledepthestimation_amd.engine import trainer as T
     from simpledepthestimation_amd.modeling import build_model
     wl = WORKLOADS[args.workload]
-    cfg = get_cfg()
+    cfg = get_project_cfg("Supervised" if wl["arch"] == "SupDepthModel" else "MonoDepth2")
     cfg.MODEL.META_ARCHITECTURE = wl["arch"]
     cfg.MODEL.DEPTH_NET.ENCODER_NAME = wl["enc"]
     cfg.MODEL.COMPUTE_DTYPE = args.dtype
     cfg.MODEL.DEVICE = str(device)
-    cfg.SOLVER.DEPTH_LR = 1e-4 if wl["arch"] == "SupDepthModel" else 2e-4
     if wl.get("packnet"):                           # projects/MonoDepth2/configs/packnet_1a.yaml
         cfg.MODEL.DEPTH_NET.NAME, cfg.MODEL.DEPTH_NET.VERSION, cfg.LOSS.VAR_LOSS_WEIGHT = "PackNet01", wl["packnet"], 1e-4
     torch.manual_seed(0)
@@ -122,6 +115,8 @@ def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50"):
     tot_ms = sum(f["ms"] for f in fam.values()); tot_fl = sum(f["flops"] for f in fam.values())
     if dom_key[0] != "igemm":
         name = "wgrad_kernel<bf16,64x128>" if dtype == "bf16" else "wgrad_kernel<f32>"
+    elif dom_key[1] >= 7000000:
+        name = f"pgemm_kernel<{dtype},{(dom_key[1] - 7000000) // 1000}x{dom_key[1] % 1000}> (persistent LDS-DMA GEMM)"
     elif dom_key[1] >= 3000000:
         name = f"halo3_kernel<{dtype},8x16 pixels x {dom_key[1] % 1000}>"
     else:
@@ -146,7 +141,10 @@ def pmc_traffic(dom_key, dtype):
         return None, None
     kind, variant = dom_key
     if kind == "igemm":
-        pat = "halo3_kernel" if variant >= 3000000 else f"igemm_kernelIDF16bLi{variant // 1000}ELi{variant % 1000}E"
+        if variant >= 7000000:
+            pat = f"pgemm_kernelILi{(variant - 7000000) // 1000}ELi{variant % 1000}E"
+        else:
+            pat = "halo3_kernel" if variant >= 3000000 else f"igemm_kernelIDF16bLi{variant // 1000}ELi{variant % 1000}E"
     elif kind == "wgrad":
         pat = "wgrad_kernelIDF16b"
     else:
@@ -168,13 +166,43 @@ def pmc_traffic(dom_key, dtype):
     return int((2.0 * f + w) * 1024), f"{os.path.basename(fetch[-1])} + {os.path.basename(write[-1])} (committed rocprofv3 --pmc passes, Supervised-R50 workload)"
 
 
+def host_cpu():
+    """CPU model and the thread count SURVEY.md 8d prescribes: the physical cores of ONE socket, capped by what this process may use."""
+    info = {}
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            info[k.strip()] = v.strip()
+    except Exception:
+        pass
+    def num(key, default):
+        try:
+            return int(info.get(key, default))
+        except ValueError:
+            return default
+    per_socket = num("Core(s) per socket", 0)
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                            # cgroup v2 CPU quota of the container, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            allowed = min(allowed, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    threads = max(1, min(per_socket or allowed, allowed))
+    return {"cpu_model": info.get("Model name", "unknown"), "sockets": num("Socket(s)", 0), "cores_per_socket": per_socket, "usable_cpus": allowed}, threads
+
+
 def cpu_baseline(args):
-    """The CPU oracle (kind "port": our torch-CPU restatement, pinned to the reference by tests/golden) on a bounded sample."""
+    """The CPU oracle (kind "port": our torch-CPU restatement, pinned to the reference by tests/golden) on a bounded sample:
+    SURVEY.md 8d protocol -- threads = physical cores of one socket, 3 warm-up + 10 timed fwd+bwd+optimizer steps."""
     from oracle import models as OM
     wl = WORKLOADS[args.workload]
     enc = int(wl["enc"])
     B, H, W = args.cpu_batch, args.height, args.width
-    torch.set_num_threads(min(32, os.cpu_count() or 1))      # small-batch CPU convolutions stop scaling (and regress) beyond a few dozen threads
+    host, threads = host_cpu()
+    if args.cpu_threads > 0:
+        threads = args.cpu_threads
+    torch.set_num_threads(threads)
     threads = torch.get_num_threads()
     if wl.get("packnet"):
         sd, enc = OM.init_packnet_state_dict(wl["packnet"][-1], seed=0), "packnet" + wl["packnet"]
@@ -195,14 +223,42 @@ def cpu_baseline(args):
             loss = out["rec_loss"] + out["smooth_loss"] + out.get("var_loss", 0.0)
         loss.backward()
         opt.step()
-    step()
+    for _ in range(args.cpu_warmup):
+        step()
     t0 = time.perf_counter()
     n = 0
     while n < args.cpu_steps:
         step(); n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n} timed fp32 training steps (fwd+bwd+optimizer) of the CPU oracle at bs={B}, {H}x{W}, after 1 warm-up step"}
+    out = {"value": round(B * n / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+           "sample": f"{n} timed fp32 training steps (fwd+bwd+optimizer) of the CPU oracle at bs={B}, {H}x{W}, after {args.cpu_warmup} warm-up steps; "
+                     f"{round(dt / n * 1e3, 1)} ms per step"}
+    out.update(host)
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (the shape of the reference's `--num-gpus N`, detectron2/engine/launch.py:L24-92): the
+    parent -- which has not touched the GPU -- starts N fresh rank processes with the torch.distributed environment, relays rank 0's JSON
+    line and fails if any rank does."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
+        sys.exit(1)
 
 
 def main():
@@ -217,12 +273,16 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline object (0 = skip)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = physical cores of one socket (SURVEY.md 8d)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-overlap", action="store_true", help="use the two-phase backward (all-reduce overlap path) even on one GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)                    # before anything in this process touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -274,6 +334,7 @@ def main():
                "config": {"workload": f"{WORKLOADS[args.workload]['desc']}, {args.dtype} storage / fp32 accumulate, bs={args.batch}/GPU, "
                                       f"{args.height}x{args.width}, fwd+bwd+optimizer, random-init weights", "global_batch": args.batch * world,
                           "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "allreduce_overlap": bool(trainer.overlap)},
+               "rccl_ranks": world,
                "final_losses": final}
         if args.profile_steps > 0:
             hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype, args.workload)

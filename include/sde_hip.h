@@ -243,10 +243,6 @@ int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B,
 int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,
                     float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream);
 
-/* torch.optim.Adam / AdamW step (projects/MonoDepth2/train.py:L50-57, projects/Supervised/train.py:L77-81) over ONE flat fp32 buffer.
- * Segment s covers [seg_end[s-1], seg_end[s]) with its own lr / weight decay (device arrays, so a captured graph sees updates);
- * bias_corr1/2 = (1 - beta1^t, 1 - beta2^t), by value (the step count lives on the host); grad_scale multiplies g first (1/world_size
- * after a sum all-reduce). */
 /* ---------------------------------------------------------------------------------------------------
  * PackNet's 3-D convolution (layers01.py:L223-298): x.unsqueeze(1) -> nn.Conv3d(1, 8, 3, padding=1) -> view(b, 8*D, h, w) on NHWC data:
  * y[b,h,w,f*D+ch] = bias[f] + sum w[f][kd][kh][kw] x[b,h+kh-1,w+kw-1,ch+kd-1].  w: [8][3][3][3] fp32 (torch's [8,1,3,3,3]), D % (16 B) == 0.
@@ -257,8 +253,27 @@ int sde_conv3d_wgrad_num_blocks(int B, int H, int W, int D, int dtype);
 int sde_conv3d_wgrad(const void* x, const void* dy, int B, int H, int W, int D, int dtype, float* part, float* dw, float* dbias, int accumulate,
                      sde_stream_t stream);
 
-int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
-                  float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale, int decoupled_wd, sde_stream_t stream);
+/* torch.optim.Adam / AdamW step (projects/MonoDepth2/train.py:L50-57, projects/Supervised/train.py:L77-81) over ONE flat fp32 buffer.
+ * The descriptor is HOST memory and is copied into the kernel arguments (nothing to upload or keep alive): segment s covers
+ * [seg_end[s-1], seg_end[s]) with its own lr / weight decay; bias_corr1/2 = (1 - beta1^t, 1 - beta2^t) (the step count lives on the host);
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ * scale_state (optional, DEVICE float[3] = {loss_scale, found_inf, growth_tracker}): fp16 training with dynamic loss scaling, the
+ * GradScaler of the reference's AMPTrainer (detectron2/engine/train_loop.py:L294-341) without its host sync: sde_grad_check raises
+ * found_inf when any gradient is inf / nan, sde_adam_step divides the gradients by loss_scale and SKIPS the whole update when found_inf
+ * is set, sde_loss_scale_update then backs the scale off (x backoff_factor) or counts towards growth (x growth_factor every
+ * growth_interval clean steps) and clears found_inf.  The loss is multiplied by scale_state[0] on the device before backward. */
+#define SDE_ADAM_MAX_SEG 8
+typedef struct sde_adam_desc {
+    long seg_end[SDE_ADAM_MAX_SEG];
+    float seg_lr[SDE_ADAM_MAX_SEG], seg_wd[SDE_ADAM_MAX_SEG];
+    int32_t nseg, decoupled_wd;
+    float beta1, beta2, eps, bias_corr1, bias_corr2, grad_scale;
+    const float* scale_state;
+} sde_adam_desc;
+int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const sde_adam_desc* d, sde_stream_t stream);
+int sde_grad_check(const float* g, long n, float* scale_state, sde_stream_t stream);
+int sde_loss_scale_update(float* scale_state, float growth_factor, float backoff_factor, int growth_interval, sde_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------------
  * Evaluation: detectron2/evaluation/depth_evaluation.py:L74-104 kitti_evaluator.process for ONE image, with

@@ -1,1 +1,1 @@
-from .config import CfgNode, get_cfg  # noqa: F401
+from .config import CfgNode, get_cfg, get_project_cfg  # noqa: F401

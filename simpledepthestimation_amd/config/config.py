@@ -142,3 +142,11 @@ def get_cfg():
     """Defaults for the keys the hot path reads (reference: detectron2/config/defaults.py:L25-40,L138-157 and SURVEY.md 8b)."""
     from .defaults import _C
     return _C.clone()
+
+
+def get_project_cfg(project):
+    """get_cfg() + the hot-path keys of projects/<project>/configs/Base.yaml ("MonoDepth2" or "Supervised"), from the embedded literals."""
+    from .defaults import PROJECT_BASE
+    cfg = get_cfg()
+    cfg.merge_from_other_cfg(copy.deepcopy(PROJECT_BASE[project]))
+    return cfg

@@ -842,23 +842,55 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
 // ------------------------------------------------------------------------------------------------------------------
 // Fused Adam / AdamW over a flat fp32 parameter buffer split into segments with their own lr / weight decay
 // ------------------------------------------------------------------------------------------------------------------
+// The whole descriptor (segment table, learning rates, bias corrections) travels BY VALUE in the kernel arguments: the host changes the
+// learning rate every iteration (polynomial decay) and nothing has to be uploaded, kept alive or ordered against the launch.
+// scale_state (optional, fp16 training): device {loss_scale, found_inf, growth_tracker}: gradients are divided by loss_scale and the
+// whole update is skipped when found_inf != 0 (engine/train_loop.py:L294-341 AMPTrainer / GradScaler.step semantics, without a host sync).
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                                                   const long* __restrict__ seg_end, const float* __restrict__ seg_lr, const float* __restrict__ seg_wd, int nseg,
-                                                   float beta1, float beta2, float eps, float bc1 /* 1-b1^t */, float bc2 /* 1-b2^t */,
-                                                   float grad_scale, int decoupled) {
+                                                   const sde_adam_desc d) {
+    float gs = d.grad_scale;
+    if (d.scale_state) {
+        if (d.scale_state[1] != 0.f) return;            // overflow in this step's gradients: skip (uniform over the grid)
+        gs /= d.scale_state[0];
+    }
+    const float beta1 = d.beta1, beta2 = d.beta2, rbc2 = 1.0f / sqrtf(d.bias_corr2);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         int s = 0;
-        while (s < nseg - 1 && i >= seg_end[s]) ++s;
-        const float lr = seg_lr[s], wd = seg_wd[s];
-        float gi = g[i] * grad_scale, pi = p[i];
-        if (decoupled) pi *= (1.0f - lr * wd);          // AdamW: torch.optim.AdamW
+        while (s < d.nseg - 1 && i >= d.seg_end[s]) ++s;
+        const float lr = d.seg_lr[s], wd = d.seg_wd[s];
+        float gi = g[i] * gs, pi = p[i];
+        if (d.decoupled_wd) pi *= (1.0f - lr * wd);     // AdamW: torch.optim.AdamW
         else gi += wd * pi;                             // Adam with L2 (wd = 0 on this path)
         const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-        p[i] = pi - (lr / bc1) * (mi / denom);
+        const float denom = sqrtf(vi) * rbc2 + d.eps;
+        p[i] = pi - (lr / d.bias_corr1) * (mi / denom);
     }
+}
+
+// found_inf = any non-finite gradient (GradScaler's unscale_/found_inf check): one pass over the flat gradient, 16 B per lane; a workgroup
+// that sees one raises state[1] (idempotent plain store of the same value: no atomics, deterministic).
+__global__ void __launch_bounds__(256) grad_check_kernel(const float4* __restrict__ g4, long n4, const float* __restrict__ tail, int ntail, float* __restrict__ state) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 q = g4[i];
+        const float t = fabsf(q.x) + fabsf(q.y) + fabsf(q.z) + fabsf(q.w);      // inf or nan in any lane makes t non-finite
+        bad |= !(t <= 3.0e38f);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) bad |= !(fabsf(tail[threadIdx.x]) <= 3.0e38f);
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[1] = 1.0f;
+}
+
+// GradScaler.update(): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and at growth_interval scale *= growth, tracker = 0.
+__global__ void loss_scale_update_kernel(float* __restrict__ state, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[1] != 0.f) { state[0] *= backoff; state[2] = 0.f; }
+    else {
+        const float t = state[2] + 1.f;
+        if (t >= (float)interval) { state[0] *= growth; state[2] = 0.f; } else state[2] = t;
+    }
+    state[1] = 0.f;
 }
 
 // If the slab has more than SDE_REDUCE_ROWS rows, fold it into SDE_REDUCE_ROWS rows stored right behind it (the caller
@@ -1092,12 +1124,29 @@ int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const floa
     return SDE_OK;
 }
 
-int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const long* seg_end, const float* seg_lr, const float* seg_wd, int nseg, float beta1,
-                  float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale, int decoupled_wd, sde_stream_t stream) {
-    SDE_CHECK_ARG(p && g && m && v && seg_end && seg_lr && seg_wd && n > 0 && nseg > 0 && bias_corr1 > 0.f && bias_corr2 > 0.f, "sde_adam_step: bad argument");
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, seg_end, seg_lr, seg_wd, nseg, beta1, beta2, eps, bias_corr1,
-                       bias_corr2, grad_scale, decoupled_wd);
+int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const sde_adam_desc* d, sde_stream_t stream) {
+    SDE_CHECK_ARG(p && g && m && v && d && n > 0, "sde_adam_step: null pointer");
+    SDE_CHECK_ARG(d->nseg > 0 && d->nseg <= SDE_ADAM_MAX_SEG && d->bias_corr1 > 0.f && d->bias_corr2 > 0.f, "sde_adam_step: bad descriptor (nseg %d)", d->nseg);
+    for (int i = 0; i < d->nseg; ++i)
+        SDE_CHECK_ARG(d->seg_end[i] > (i ? d->seg_end[i - 1] : 0) && d->seg_end[i] <= n, "sde_adam_step: segment %d ends at %ld (n = %ld)", i, d->seg_end[i], n);
+    SDE_CHECK_ARG(d->seg_end[d->nseg - 1] == n, "sde_adam_step: the segments must cover the buffer");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, *d);
     SDE_CHECK_LAUNCH("sde_adam_step");
+    return SDE_OK;
+}
+
+int sde_grad_check(const float* g, long n, float* scale_state, sde_stream_t stream) {
+    SDE_CHECK_ARG(g && scale_state && n > 0 && ((uintptr_t)g & 15) == 0, "sde_grad_check: bad argument");
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(grad_check_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(256), 0, (hipStream_t)stream, (const float4*)g, n4, g + n4 * 4, (int)(n - n4 * 4), scale_state);
+    SDE_CHECK_LAUNCH("sde_grad_check");
+    return SDE_OK;
+}
+
+int sde_loss_scale_update(float* scale_state, float growth_factor, float backoff_factor, int growth_interval, sde_stream_t stream) {
+    SDE_CHECK_ARG(scale_state && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0, "sde_loss_scale_update: bad argument");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale_state, growth_factor, backoff_factor, growth_interval);
+    SDE_CHECK_LAUNCH("sde_loss_scale_update");
     return SDE_OK;
 }
 

@@ -70,7 +70,10 @@ class _LossMeter:
 
 
 def do_test(cfg, model, data_loader_test):
-    return inference_on_dataset(model, data_loader_test, build_evaluator(cfg, os.path.join(cfg.OUTPUT_DIR, "inference")))
+    # projects/*/train.py:L62-66: OUTPUT_DIR/inference/<DATASETS.TEST.NAME>
+    name = cfg.DATASETS.TEST.get("NAME", "") if ("DATASETS" in cfg and "TEST" in cfg.DATASETS) else ""
+    return inference_on_dataset(model, data_loader_test, build_evaluator(cfg, os.path.join(cfg.OUTPUT_DIR, "inference", name) if name else
+                                                                         os.path.join(cfg.OUTPUT_DIR, "inference")))
 
 
 def do_train(cfg, model, data_loader, data_loader_test=None, resume=False, use_graph=None):

@@ -18,6 +18,7 @@ MI355X-first choices
 import math
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -56,7 +57,7 @@ class HipTrainer:
     """Owns the flat buffers and runs one training step: loss dict = trainer.step(batch)."""
 
     def __init__(self, model, groups, adamw=False, betas=(0.9, 0.999), eps=1e-8, bucket_mb=64, use_graph=False, skip_unused=(".fc.",),
-                 adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None):
+                 adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None, amp=False, init_scale=65536.0, growth_interval=2000):
         self.model = model
         self._adam_fn = adam_fn or HN.adam_step      # tests on CPU (gloo) substitute a torch restatement of the same update
         self.adamw, self.betas, self.eps = bool(adamw), betas, float(eps)
@@ -66,10 +67,12 @@ class HipTrainer:
         self.device = dev
         # ---- flatten: parameters of each group become views of one buffer, in group order
         self.groups = []
-        total = 0
+        self._all_names = []           # per group: EVERY parameter name in registration order, incl. the skipped ones (torchvision's unused fc):
+        total = 0                      # a torch.optim state dict of the reference numbers its parameters over that full list
         for g in groups:
             kept = [(n, p) for n, p in g.named_params if p.requires_grad and not any(s in n for s in skip_unused)]
             self.groups.append(ParamGroup(g.name, kept, g.lr, g.weight_decay))
+            self._all_names.append([n for n, _ in g.named_params])
             total += sum(p.numel() for _, p in kept)
         self.numel = total
         self.pflat = torch.empty(total, device=dev, dtype=torch.float32)
@@ -85,10 +88,12 @@ class HipTrainer:
                 p.grad = self.gflat[off:off + n].view(p.shape)
                 off += n
             seg_end.append(off)
-        self.seg_end = torch.tensor(seg_end, dtype=torch.long, device=dev)
-        self.seg_lr = torch.tensor([g.lr for g in self.groups], dtype=torch.float32, device=dev)
-        self.seg_wd = torch.tensor([g.weight_decay for g in self.groups], dtype=torch.float32, device=dev)
+        self.seg_end = seg_end         # host tables: the optimizer kernel takes them by value (no upload to order against the launch)
         self.t = 0
+        # fp16 training (SOLVER.AMP, detectron2/engine/train_loop.py:L294-341): device-side GradScaler state {scale, found_inf, growth tracker}
+        self.amp = bool(amp)
+        self.growth_interval = int(growth_interval)
+        self.scale_state = torch.tensor([float(init_scale), 0.0, 0.0], device=dev, dtype=torch.float32) if self.amp else None
         # ---- gradient buckets for the all-reduce (contiguous slices of the flat gradient)
         per = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = [(s, min(total, s + per)) for s in range(0, total, per)]
@@ -112,6 +117,7 @@ class HipTrainer:
             self.overlap = False
         self._graph_b = None
         self._graph = None
+        self._graphs = {}
         self._static_batch = None
         self._static_out = None
         self._packer = None            # built lazily after the first eager step (needs the operand shapes seen in forward)
@@ -121,8 +127,9 @@ class HipTrainer:
 
     # ------------------------------------------------------------------------------------------------------------
     def set_lr(self, lrs):
-        """lrs: one value per group (device tensor update, visible to the next optimizer launch)."""
-        self.seg_lr.copy_(torch.tensor([float(x) for x in lrs], dtype=torch.float32), non_blocking=True)
+        """lrs: one value per group.  Host-side only: the next optimizer launch carries the values in its kernel arguments."""
+        if len(lrs) != len(self.groups):
+            raise ValueError(f"set_lr: {len(lrs)} values for {len(self.groups)} parameter groups")
         for g, lr in zip(self.groups, lrs):
             g.lr = float(lr)
 
@@ -144,39 +151,58 @@ class HipTrainer:
                 off += n
             groups.append({"lr": g.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": g.weight_decay, "amsgrad": False,
                            "params": ids, "param_names": [n for n, _ in g.named_params], "name": g.name})
-        return {"state": state, "param_groups": groups}
+        out = {"state": state, "param_groups": groups}
+        if self.amp:                                   # GradScaler.state_dict(): the one host read of the scale, at checkpoint time
+            sc = self.scale_state.detach().cpu().tolist()
+            out["loss_scale"], out["growth_tracker"] = sc[0], sc[2]
+        return out
 
     def load_state_dict(self, sd):
         """Accepts what state_dict() writes and what torch.optim.Adam(W).state_dict() of the reference's optimizer writes (same groups,
-        same order).  Within a group parameters are matched by 'param_names' when present, otherwise by position; entries whose shape
-        does not match the parameter at that position are a ValueError (nothing is loaded silently into the wrong tensor)."""
+        same order).  Within a group parameters are matched by 'param_names' when present, otherwise by their position in the group's FULL
+        registration order -- the reference's groups also hold torchvision's unused fc.weight / fc.bias (in the middle of MonoDepth2's
+        'Depth' group), which this trainer skips but which still occupy positions in the file.  Everything is validated before the first
+        write: a mismatch raises ValueError and leaves the moments untouched."""
         their_groups = sd["param_groups"]
         if len(their_groups) != len(self.groups):
             raise ValueError(f"optimizer checkpoint has {len(their_groups)} parameter groups, this trainer {len(self.groups)}")
         state = {int(k): v for k, v in sd["state"].items()}
-        steps, off = [], 0
-        self.m.zero_()
-        self.v.zero_()
-        for g, tg in zip(self.groups, their_groups):
+        plan, steps, off = [], [], 0
+        for g, tg, all_names in zip(self.groups, their_groups, self._all_names):
             names = tg.get("param_names")
-            by_name = dict(zip(names, tg["params"])) if names else None
-            for pos, (n, p) in enumerate(g.named_params):
+            ids = list(tg["params"])
+            if names:
+                by_name = dict(zip(names, ids))
+            elif len(ids) == len(all_names):
+                by_name = dict(zip(all_names, ids))                       # the reference's numbering: every registered parameter, fc included
+            elif len(ids) == len(g.named_params):
+                by_name = dict(zip([n for n, _ in g.named_params], ids))    # a file written over the kept parameters only
+            else:
+                raise ValueError(f"optimizer group '{g.name}': checkpoint lists {len(ids)} parameters, the model registers {len(all_names)} "
+                                 f"({len(g.named_params)} of them trained)")
+            for n, p in g.named_params:
                 k = p.numel()
-                pid = by_name.get(n) if by_name is not None else (tg["params"][pos] if pos < len(tg["params"]) else None)
-                ent = state.get(pid) if pid is not None else None
+                ent = state.get(by_name.get(n))
                 if ent is not None:
-                    if tuple(ent["exp_avg"].shape) != tuple(p.shape):
-                        raise ValueError(f"optimizer state {pid} has shape {tuple(ent['exp_avg'].shape)}, parameter '{n}' {tuple(p.shape)}")
-                    self.m[off:off + k].copy_(ent["exp_avg"].reshape(-1).to(self.m))
-                    self.v[off:off + k].copy_(ent["exp_avg_sq"].reshape(-1).to(self.v))
+                    for key in ("exp_avg", "exp_avg_sq"):
+                        if tuple(ent[key].shape) != tuple(p.shape):
+                            raise ValueError(f"optimizer state {by_name.get(n)} ({key}) has shape {tuple(ent[key].shape)}, parameter '{n}' {tuple(p.shape)}")
+                    plan.append((off, k, ent))
                     steps.append(int(float(ent["step"])))
                 off += k
-            g.lr, g.weight_decay = float(tg.get("lr", g.lr)), float(tg.get("weight_decay", g.weight_decay))
         if steps and min(steps) != max(steps):
             raise ValueError("per-parameter step counts differ; the fused Adam kernel keeps one step count for all parameters")
+        # ---- validated: now write
+        self.m.zero_()
+        self.v.zero_()
+        for off, k, ent in plan:
+            self.m[off:off + k].copy_(ent["exp_avg"].reshape(-1).to(self.m))
+            self.v[off:off + k].copy_(ent["exp_avg_sq"].reshape(-1).to(self.v))
+        for g, tg in zip(self.groups, their_groups):
+            g.lr, g.weight_decay = float(tg.get("lr", g.lr)), float(tg.get("weight_decay", g.weight_decay))
         self.t = steps[0] if steps else 0
-        self.seg_lr.copy_(torch.tensor([g.lr for g in self.groups], dtype=torch.float32))
-        self.seg_wd.copy_(torch.tensor([g.weight_decay for g in self.groups], dtype=torch.float32))
+        if self.amp and "loss_scale" in sd:
+            self.scale_state.copy_(torch.tensor([float(sd["loss_scale"]), 0.0, float(sd.get("growth_tracker", 0.0))]))
 
     def _fwd_bwd(self, batch):
         self.gflat.zero_()
@@ -185,6 +211,8 @@ class HipTrainer:
         out = self.model(batch)
         loss_dict = {k: v for k, v in out.items() if "loss" in k}
         losses = sum(loss_dict.values())
+        if self.amp:
+            losses = losses * self.scale_state[0]       # GradScaler.scale(loss): a device scalar, so the multiply is part of the captured graph
         if self._packer is not None:
             self._packer.join_dgrad()
         self._backward(lambda: losses.backward())
@@ -198,12 +226,16 @@ class HipTrainer:
     def _backward(self, run):
         """One backward phase with the convolutions' weight-gradient reductions deferred to a single launch at its end."""
         HN.WGRAD_DEFER = self._wreduce
+        # the fork / lagging-join bookkeeping of the weight-gradient side stream (hip/nn.py) is written against ONE main stream: every
+        # convolution's backward must run on the stream this phase started on
+        HN.MAIN_STREAM = torch.cuda.current_stream() if self.device.type == "cuda" else None
         try:
             run()
             if self._wreduce is not None:
                 self._wreduce.flush()
         finally:
             HN.WGRAD_DEFER = None
+            HN.MAIN_STREAM = None
             if self._wreduce is not None:
                 self._wreduce.join_pending()
                 if self._wreduce.forked:                                  # backward raised before the flush: still join the side stream
@@ -235,41 +267,81 @@ class HipTrainer:
         self.t += 1
         b1, b2 = self.betas
         bias_corr = (1.0 - b1 ** self.t, 1.0 - b2 ** self.t)       # by value: no per-step device scalar to keep ordered with the launch
-        self._adam_fn(self.pflat, self.gflat, self.m, self.v, self.seg_end, self.seg_lr, self.seg_wd, bias_corr, b1, b2, self.eps,
-                      1.0 / self.world, self.adamw)
+        lrs, wds = [g.lr for g in self.groups], [g.weight_decay for g in self.groups]
+        if self.amp:
+            # GradScaler.step + update without a host sync: the check raises found_inf on the device, the optimizer kernel divides by the
+            # scale and skips itself on overflow, the update kernel backs the scale off or counts towards growth
+            HN.grad_check(self.gflat, self.scale_state)
+            self._adam_fn(self.pflat, self.gflat, self.m, self.v, self.seg_end, lrs, wds, bias_corr, b1, b2, self.eps, 1.0 / self.world, self.adamw,
+                          scale_state=self.scale_state)
+            HN.loss_scale_update(self.scale_state, 2.0, 0.5, self.growth_interval)
+        else:
+            self._adam_fn(self.pflat, self.gflat, self.m, self.v, self.seg_end, lrs, wds, bias_corr, b1, b2, self.eps, 1.0 / self.world, self.adamw)
 
     # ------------------------------------------------------------------------------------------------------------
+    # ---- hipGraph path: the batch dicts of the reference's collate (data/datasets/kitti_v2.py:L196-221) hold, besides tensors, numpy
+    # arrays (ctx_img / ctx_img_orig lists), python scalars that steer the model (`flip`: ONE bool per batch) and per-sample
+    # bookkeeping the kernels never read (`metadata`: list of dicts, file names).  Arrays become device tensors with static addresses;
+    # steering scalars select the graph set (one capture per distinct value, lazily); everything else passes through by reference.
+    @staticmethod
+    def _is_array(v):
+        return torch.is_tensor(v) or isinstance(v, np.ndarray)
+
+    @classmethod
+    def _kind(cls, v):
+        if cls._is_array(v):
+            return "array"
+        if isinstance(v, (list, tuple)) and len(v) > 0 and all(cls._is_array(x) for x in v):
+            return "arrays"
+        if isinstance(v, (bool, int, float, str, type(None), np.bool_, np.integer, np.floating)):
+            return "scalar"
+        return "opaque"
+
+    def _graph_key(self, batch):
+        return tuple(sorted((k, v.item() if isinstance(v, np.generic) else v) for k, v in batch.items() if self._kind(v) == "scalar"))
+
     def _to_static(self, batch):
         def conv(v):
-            if torch.is_tensor(v):
-                return v.to(self.device).clone()
-            if isinstance(v, list):
-                return [conv(x) for x in v]
-            return v
-        return {k: conv(v) for k, v in batch.items()}
+            return torch.as_tensor(v).to(self.device).clone()
+        out = {}
+        for k, v in batch.items():
+            kind = self._kind(v)
+            out[k] = conv(v) if kind == "array" else ([conv(x) for x in v] if kind == "arrays" else v)
+        return out
 
     def _staged(self, v):
         """The static batch may still be read by the previous replay: never write pageable host data straight into it.  Pageable
         tensors first land in a fresh device tensor (blocking copy), the copy into the static buffer is then device-to-device in
         stream order; pinned and device tensors are already stream-ordered."""
+        v = torch.as_tensor(v)
         if v.device.type == "cpu" and not v.is_pinned():
             return v.to(self.device)
         return v
 
     def _copy_into_static(self, batch):
+        if set(batch.keys()) != set(self._static_batch.keys()):
+            raise RuntimeError(f"batch keys changed since capture: {sorted(batch.keys())} vs {sorted(self._static_batch.keys())}")
         for k, v in batch.items():
-            s = self._static_batch[k]
-            if torch.is_tensor(v):
+            s, kind = self._static_batch[k], self._kind(v)
+            if kind == "array":
                 s.copy_(self._staged(v), non_blocking=True)
-            elif isinstance(v, list):
+            elif kind == "arrays":
+                if len(s) != len(v):
+                    raise RuntimeError(f"batch entry '{k}' changed length ({len(s)} -> {len(v)})")
                 for a, b in zip(s, v):
-                    a.copy_(self._staged(b if torch.is_tensor(b) else torch.as_tensor(b)), non_blocking=True)
-            elif s != v:
-                raise RuntimeError(f"non-tensor batch entry '{k}' changed ({s} -> {v}); re-capture the graph")
+                    a.copy_(self._staged(b), non_blocking=True)
+            else:
+                self._static_batch[k] = v          # steering scalars are part of the graph key; opaque entries are not read by captured work
 
     def capture(self, batch, warmup=3):
-        """Warm up eagerly (sets kernel attributes, fills the allocator), then capture zero-grad + forward + backward."""
-        self._static_batch = self._to_static(batch)
+        """Warm up eagerly (sets kernel attributes, fills the allocator), then capture zero-grad + forward + backward for this batch's
+        steering scalars (e.g. flip = False); other values get their own graph set on first use, over the same static input tensors."""
+        if self._static_batch is None:
+            self._static_batch = self._to_static(batch)
+            self._graphs = {}
+        else:
+            self._copy_into_static(batch)
+        key = self._graph_key(batch)
         # the warm-up steps and the capture pass must leave no trace in the model: BatchNorm running statistics (updated by every
         # training-mode forward) and the host-side batch counters are put back afterwards, so step k of a captured run sees exactly
         # the buffers step k of an eager run sees (and a resumed run continues from what the checkpoint held)
@@ -285,26 +357,31 @@ class HipTrainer:
                     self._backward_rest()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._static_out = self._fwd_bwd(dict(self._static_batch))
+        graph, graph_b = torch.cuda.CUDAGraph(), None
+        with torch.cuda.graph(graph):
+            static_out = self._fwd_bwd(dict(self._static_batch))
         if self._cut is not None:                  # phase B: the rest of backward, same memory pool, replayed after phase A
-            self._graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_b, pool=self._graph.pool()):
+            graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_b, pool=graph.pool()):
                 self._backward_rest()
         with torch.no_grad():
             for b, k in zip(self.model.buffers(), kept_buffers):
                 b.copy_(k)
         for m, k in zip(self._bns, kept_counts):
             m._pending_batches = k
+        self._graphs[key] = (graph, graph_b, static_out)
+        self._graph, self._graph_b, self._static_out = graph, graph_b, static_out
         return self
 
     def step(self, batch):
         """One optimisation step.  Returns {loss name: 0-d device tensor} (no host sync)."""
         if self.use_graph:
-            if self._graph is None:
-                self.capture(batch)
-            self._copy_into_static(batch)
+            hit = self._graphs.get(self._graph_key(batch)) if self._static_batch is not None else None
+            if hit is None:
+                self.capture(batch)                 # first batch, or a steering value (flip) not seen before; leaves the batch in the static buffers
+            else:
+                self._graph, self._graph_b, self._static_out = hit
+                self._copy_into_static(batch)
             self._graph.replay()
             for m in self._bns:                     # the replay runs no Python forward: count the batch for num_batches_tracked here
                 m._pending_batches += 1
@@ -327,12 +404,20 @@ class HipTrainer:
         return loss_dict
 
 
+def _amp_kw(cfg, kw):
+    if bool(cfg.SOLVER.get("AMP", False)):
+        if str(cfg.MODEL.get("COMPUTE_DTYPE", "fp32")) != "fp16":
+            raise ValueError("SOLVER.AMP needs MODEL.COMPUTE_DTYPE fp16 (bf16 and fp32 need no loss scaling)")
+        kw.setdefault("amp", True)
+    return kw
+
+
 def supervised_trainer(model, cfg, **kw):
     """AdamW(enc wd 1e-2, dec wd 0, lr DEPTH_LR, eps 1e-6) -- projects/Supervised/train.py:L77-81."""
     m = model.module if hasattr(model, "module") else model
     groups = [ParamGroup("encoder", m.depth_net.encoder.named_parameters(prefix="depth_net.encoder"), cfg.SOLVER.DEPTH_LR, 1e-2),
               ParamGroup("decoder", m.depth_net.decoder.named_parameters(prefix="depth_net.decoder"), cfg.SOLVER.DEPTH_LR, 0.0)]
-    return HipTrainer(m, groups, adamw=True, eps=1e-6, **kw)
+    return HipTrainer(m, groups, adamw=True, eps=1e-6, **_amp_kw(cfg, kw))
 
 
 def monodepth2_trainer(model, cfg, **kw):
@@ -340,7 +425,7 @@ def monodepth2_trainer(model, cfg, **kw):
     m = model.module if hasattr(model, "module") else model
     groups = [ParamGroup("Depth", m.depth_net.named_parameters(prefix="depth_net"), cfg.SOLVER.DEPTH_LR, 0.0),
               ParamGroup("Pose", m.pose_net.named_parameters(prefix="pose_net"), cfg.SOLVER.POSE_LR, 0.0)]
-    return HipTrainer(m, groups, adamw=False, eps=1e-8, **kw)
+    return HipTrainer(m, groups, adamw=False, eps=1e-8, **_amp_kw(cfg, kw))
 
 
 def poly_lr(cfg, global_step, max_iter):

@@ -35,6 +35,19 @@ def _nearest(src, dst):
     return np.minimum(np.floor(np.arange(dst, dtype=np.float64) * step).astype(np.int64), src - 1).astype(np.int32)
 
 
+def _as_int(v):
+    """Integer-like metadata value (python / numpy int, 0-d integer tensor or array) as a python int, else None."""
+    if isinstance(v, (bool, np.bool_)):
+        return None
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if torch.is_tensor(v) and v.ndim == 0 and not v.is_floating_point() and not v.is_complex():
+        return int(v.item())
+    if isinstance(v, np.ndarray) and v.ndim == 0 and np.issubdtype(v.dtype, np.integer):
+        return int(v)
+    return None
+
+
 def backward_maps(pred_hw, metadata, chain):
     """The postprocess.backward() chain (augmentation.py: Resize L163-166, KBCrop L67-74, CropTopTo L113-120) as (ymap, xmap) int32 arrays:
     which network-output row / column each row / column of the restored full-size map shows; -1 where the reference pastes zeros."""
@@ -73,7 +86,7 @@ class kitti_evaluator(DatasetEvaluator):
 
     def _device_maps(self, pred_hw, gt_hw, meta, device):
         chain = self.preprocess_chain
-        key = (pred_hw, gt_hw, tuple(chain), tuple(sorted((k, v) for k, v in meta.items() if isinstance(v, (int, np.integer)))))
+        key = (pred_hw, gt_hw, tuple(chain), tuple(sorted((k, _as_int(v)) for k, v in meta.items() if _as_int(v) is not None)))
         hit = self._maps.get(key)
         if hit is None:
             if chain:
@@ -143,6 +156,16 @@ def write_depth(depth, save_path):
     Image.fromarray(scaled).save(save_path, format="PNG", compress_level=3)
 
 
+def np_median(t):
+    """np.median of a 1-D tensor (depth_evaluation.py:L96-97 uses numpy): the MEAN of the two middle elements for an even count --
+    torch.Tensor.median() would return the lower one."""
+    n = t.numel()
+    if n == 0:
+        return t.new_tensor(float("nan"))
+    s = torch.sort(t.reshape(-1).float())[0]
+    return (s[(n - 1) // 2] + s[n // 2]) * 0.5
+
+
 @EVALUATOR_REGISTRY.register()
 class kitti_depth_saver(DatasetEvaluator):
     """Saves every prediction, restored to the original image size by the same index maps the metric evaluators use (depth_evaluation.py:L163-203),
@@ -167,7 +190,7 @@ class kitti_depth_saver(DatasetEvaluator):
             if self.use_gt_scale and "depth_gt_orig" in inputs:
                 gt = torch.as_tensor(inputs["depth_gt_orig"][i]).squeeze().to(full.device, torch.float32)
                 valid = (gt > 1e-3) & (gt < 80)
-                full = full * gt[valid].median() / full[valid].median()
+                full = full * np_median(gt[valid]) / np_median(full[valid])
             name = f"{meta['date']}_{meta['drive']}_{meta['img_id']}.png"
             os.makedirs(self.output_folder, exist_ok=True)
             write_depth(full.cpu().numpy(), os.path.join(self.output_folder, name))

@@ -33,7 +33,8 @@ class DatasetEvaluator:
     def __init__(self, cfg=None):
         # names of the test-time preprocess steps, forward order; their backward() chain is folded into index maps by the evaluators
         steps = cfg.DATASETS.TEST.get("PREPROCESS", []) if (cfg is not None and "DATASETS" in cfg and "TEST" in cfg.DATASETS) else []
-        self.preprocess_chain = [s["NAME"] if isinstance(s, dict) else s.NAME for s in steps]
+        names = [s["NAME"] if isinstance(s, dict) else s.NAME for s in steps]
+        self.preprocess_chain = [n for n in names if n in ("Resize", "KBCrop", "CropTopTo")]      # the steps that have a backward() (augmentation.py:L67,L113,L163)
 
     def reset(self):
         pass

@@ -56,7 +56,9 @@ L.register_protos({
     "sde_conv3d_dgrad": ([_P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_conv3d_wgrad_num_blocks": ([_I, _I, _I, _I, _I], c_int),
     "sde_conv3d_wgrad": ([_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P], c_int),
-    "sde_adam_step": ([_P, _P, _P, _P, _LG, _P, _P, _P, _I, _F, _F, _F, _F, _F, _F, _I, _P], c_int),
+    "sde_adam_step": ([_P, _P, _P, _P, _LG, _P, _P], c_int),
+    "sde_grad_check": ([_P, _LG, _P, _P], c_int),
+    "sde_loss_scale_update": ([_P, _F, _F, _I, _P], c_int),
 })
 
 
@@ -204,6 +206,11 @@ class _Conv2d(torch.autograd.Function):
         ldy = pad_to(Cout, V)
         if dy is None:
             return (None,) * 11
+        if MAIN_STREAM is not None and torch.cuda.current_stream() != MAIN_STREAM:
+            # e.g. part of the forward pass ran under torch.cuda.stream(helper): autograd then replays this node's backward on that stream,
+            # underneath fork / join events recorded against the trainer's stream (operands could be recycled while a GEMM still reads them)
+            raise L.SdeHipError("conv2d backward is running on a different stream than the one the backward phase started on; the "
+                                "weight-gradient side-stream bookkeeping supports one main stream only")
         dy = dy.contiguous()
         M = B * OH * OW
         flops = 2.0 * M * Cout * KH * KW * Cin                    # algorithmic FLOPs of each of dgrad / wgrad
@@ -429,6 +436,7 @@ class WGradReducer:
 
 
 WGRAD_DEFER = None      # HipTrainer installs a WGradReducer around backward
+MAIN_STREAM = None      # ... and the stream the backward phase runs on: the side-stream fork / lagging-join bookkeeping assumes ONE main stream
 FOLD_ROWS = 16          # SDE_WGRAD_FOLD_ROWS
 
 
@@ -736,7 +744,35 @@ def conv3d_pack(x, weight, bias):
 # ---------------------------------------------------------------------------------------------------------------
 # Fused Adam / AdamW over a flat buffer
 # ---------------------------------------------------------------------------------------------------------------
-def adam_step(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, decoupled_wd=False):
-    n = p.numel()
-    L.check(L.lib().sde_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, L.ptr(seg_end), L.ptr(seg_lr), L.ptr(seg_wd), seg_end.numel(), beta1, beta2, eps,
-                                  float(bias_corr[0]), float(bias_corr[1]), grad_scale, int(decoupled_wd), L.stream()), "sde_adam_step")
+ADAM_MAX_SEG = 8       # SDE_ADAM_MAX_SEG
+
+
+class AdamDesc(Structure):
+    _fields_ = [("seg_end", c_long * ADAM_MAX_SEG), ("seg_lr", c_float * ADAM_MAX_SEG), ("seg_wd", c_float * ADAM_MAX_SEG), ("nseg", c_int32),
+                ("decoupled_wd", c_int32), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("bias_corr1", c_float), ("bias_corr2", c_float),
+                ("grad_scale", c_float), ("scale_state", c_void_p)]
+
+
+def adam_step(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, decoupled_wd=False, scale_state=None):
+    """seg_end / seg_lr / seg_wd: HOST sequences (one entry per segment); everything travels by value in the kernel arguments.
+    scale_state: optional device float[3] {loss_scale, found_inf, growth_tracker} (fp16 dynamic loss scaling)."""
+    nseg = len(seg_end)
+    if not (0 < nseg <= ADAM_MAX_SEG and len(seg_lr) == nseg and len(seg_wd) == nseg):
+        raise L.SdeHipError(f"adam_step: {nseg} segments (at most {ADAM_MAX_SEG})")
+    d = AdamDesc()
+    for i in range(nseg):
+        d.seg_end[i], d.seg_lr[i], d.seg_wd[i] = int(seg_end[i]), float(seg_lr[i]), float(seg_wd[i])
+    d.nseg, d.decoupled_wd = nseg, int(bool(decoupled_wd))
+    d.beta1, d.beta2, d.eps, d.bias_corr1, d.bias_corr2, d.grad_scale = beta1, beta2, eps, float(bias_corr[0]), float(bias_corr[1]), grad_scale
+    d.scale_state = scale_state.data_ptr() if scale_state is not None else None
+    L.check(L.lib().sde_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), ctypes.byref(d), L.stream()), "sde_adam_step")
+
+
+def grad_check(g, scale_state):
+    """scale_state[1] = 1 when any element of the flat fp32 gradient is inf / nan (device side, no host sync)."""
+    L.check(L.lib().sde_grad_check(L.ptr(g), g.numel(), L.ptr(scale_state), L.stream()), "sde_grad_check")
+
+
+def loss_scale_update(scale_state, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+    """torch.cuda.amp.GradScaler.update() on the device scalar triple."""
+    L.check(L.lib().sde_loss_scale_update(L.ptr(scale_state), growth_factor, backoff_factor, int(growth_interval), L.stream()), "sde_loss_scale_update")

@@ -41,6 +41,11 @@ def mod():
 
 
 @pytest.fixture(scope="session")
+def mono50():
+    return _Golden(os.path.join(GOLDEN, "mono50.npz"))
+
+
+@pytest.fixture(scope="session")
 def pack():
     return _Golden(os.path.join(GOLDEN, "packnet.npz"))
 

@@ -170,3 +170,79 @@ def test_reference_keyed_checkpoint_loads_into_the_hip_models(tmp_path, arch, la
     for k, v in model.state_dict().items():
         if k in sd:
             assert torch.equal(v.cpu(), sd[k].to(v.dtype)), k
+
+
+class WithFc(nn.Module):
+    """Mirrors the reference's MonoDepth2 'Depth' group (projects/MonoDepth2/train.py:L51-53: depth_net.parameters()): torchvision's unused
+    classifier sits in the MIDDLE of the group (encoder ... encoder.fc, decoder ...), never receives a gradient, and the trainer skips it."""
+
+    def __init__(self):
+        super().__init__()
+        self.depth_net = nn.Module()
+        self.depth_net.encoder = nn.Module()
+        self.depth_net.encoder.conv = nn.Linear(6, 5)
+        self.depth_net.encoder.fc = nn.Linear(5, 3)           # unused, like depth_net.encoder.encoder.fc
+        self.depth_net.decoder = nn.Module()
+        self.depth_net.decoder.a = nn.Linear(5, 5)            # same shape as ...
+        self.depth_net.decoder.b = nn.Linear(5, 5)            # ... its neighbour: a positional shift would go unnoticed by a shape check
+        self.pose_net = nn.Linear(5, 1)
+
+    def forward(self, batch):
+        h = torch.tanh(self.depth_net.encoder.conv(batch["x"]))
+        h = torch.tanh(self.depth_net.decoder.b(torch.tanh(self.depth_net.decoder.a(h))))
+        return {"mse_loss": ((self.pose_net(h).squeeze(-1) - batch["t"]) ** 2).mean()}
+
+
+def _fc_trainer(model):
+    groups = [ParamGroup("Depth", model.depth_net.named_parameters(prefix="depth_net"), 2e-3, 0.0),
+              ParamGroup("Pose", model.pose_net.named_parameters(prefix="pose_net"), 1e-3, 0.0)]
+    return HipTrainer(model, groups, adamw=False, eps=1e-8, adam_fn=torch_adam)
+
+
+def test_reference_optimizer_state_with_unused_fc_in_the_middle_of_a_group(tmp_path):
+    """torch.optim.Adam over depth_net.parameters() + pose_net.parameters() (the reference's MonoDepth2 optimizer): fc.weight / fc.bias occupy
+    positions 2 and 3 of the 'Depth' group and have no state.  The trainer must map every later parameter by its position in the FULL
+    registration order and continue torch's trajectory exactly."""
+    torch.manual_seed(11)
+    ref = WithFc()
+    opt = torch.optim.Adam([{"params": list(ref.depth_net.parameters()), "lr": 2e-3, "weight_decay": 0.0},
+                            {"params": list(ref.pose_net.parameters()), "lr": 1e-3, "weight_decay": 0.0}])
+    for i in range(3):
+        opt.zero_grad(); ref(_batch(i))["mse_loss"].backward(); opt.step()
+    osd = opt.state_dict()
+    assert len(osd["param_groups"][0]["params"]) == 8 and 2 not in osd["state"] and 3 not in osd["state"]      # fc holds positions, not state
+    torch.manual_seed(99)
+    model = WithFc(); model.load_state_dict(ref.state_dict())
+    tr = _fc_trainer(model)
+    assert [n for n, _ in tr.groups[0].named_params] == ["depth_net.encoder.conv.weight", "depth_net.encoder.conv.bias", "depth_net.decoder.a.weight",
+                                                        "depth_net.decoder.a.bias", "depth_net.decoder.b.weight", "depth_net.decoder.b.bias"]
+    tr.load_state_dict(osd)
+    assert tr.t == 3
+    # decoder.a's moments are torch's entry 4 (not 2, which a count over the kept parameters only would pick)
+    off = sum(p.numel() for _, p in tr.groups[0].named_params[:2])
+    assert torch.equal(tr.m[off:off + 25].view(5, 5), osd["state"][4]["exp_avg"])
+    for i in range(3, 6):
+        tr.step(_batch(i))
+        opt.zero_grad(); ref(_batch(i))["mse_loss"].backward(); opt.step()
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_optimizer_state_is_validated_before_anything_is_written():
+    torch.manual_seed(2)
+    model = WithFc(); tr = _fc_trainer(model)
+    for i in range(2):
+        tr.step(_batch(i))
+    m0, v0, t0 = tr.m.clone(), tr.v.clone(), tr.t
+    sd = tr.state_dict()
+    last = max(sd["state"])
+    sd["state"][last]["exp_avg_sq"] = torch.zeros(3, 3)          # wrong shape at the very end
+    with pytest.raises(ValueError):
+        tr.load_state_dict(sd)
+    assert torch.equal(tr.m, m0) and torch.equal(tr.v, v0) and tr.t == t0      # nothing half-loaded
+    sd = tr.state_dict()
+    sd["param_groups"][0].pop("param_names")
+    sd["param_groups"][0]["params"] = sd["param_groups"][0]["params"][:-1]      # neither the full nor the trained count
+    with pytest.raises(ValueError):
+        tr.load_state_dict(sd)
+    assert torch.equal(tr.m, m0) and torch.equal(tr.v, v0)

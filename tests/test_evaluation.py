@@ -60,9 +60,9 @@ def test_host_maps_and_windows_match_oracle():
 
 
 def test_registry_and_config_surface():
-    from simpledepthestimation_amd.config import get_cfg
+    from simpledepthestimation_amd.config import get_project_cfg
     from simpledepthestimation_amd.evaluation import EVALUATOR_REGISTRY, DatasetEvaluator, build_evaluator
-    cfg = get_cfg()
+    cfg = get_project_cfg("MonoDepth2")
     evs = build_evaluator(cfg, None)
     assert [type(e).__name__ for e in evs] == list(cfg.EVALUATORS) and all(isinstance(e, DatasetEvaluator) for e in evs)
     assert [(e.min_depth, e.max_depth, e.tag) for e in evs] == [(1e-3, 80, "kitti evaluator"), (1e-3, 30, "kitti evaluator (0-30m)"),
@@ -123,9 +123,9 @@ def test_kernel_edge_cases():
 @pytest.mark.parametrize("gt_scale", [False, True])
 def test_evaluators_end_to_end_vs_oracle(evg, gt_scale):
     """process() over two batches (KITTI-sized images of different sizes + one image without valid ground truth) == the oracle's loop."""
-    from simpledepthestimation_amd.config import get_cfg
+    from simpledepthestimation_amd.config import get_project_cfg
     from simpledepthestimation_amd.evaluation import DatasetEvaluators, build_evaluator
-    cfg = get_cfg(); cfg.TEST.GT_SCALE = gt_scale
+    cfg = get_project_cfg("MonoDepth2"); cfg.TEST.GT_SCALE = gt_scale
     evs = build_evaluator(cfg, None)
     both = DatasetEvaluators(evs)
     both.reset()
@@ -155,10 +155,11 @@ def test_evaluators_end_to_end_vs_oracle(evg, gt_scale):
 def test_inference_on_dataset_runs_the_model_in_eval_mode():
     from oracle import models as OM
     from oracle.gen_golden import sup_batch
-    from simpledepthestimation_amd.config import get_cfg
+    from simpledepthestimation_amd.config import get_project_cfg
     from simpledepthestimation_amd.evaluation import build_evaluator, inference_on_dataset
     from simpledepthestimation_amd.modeling import build_model
-    cfg = get_cfg(); cfg.MODEL.META_ARCHITECTURE = "SupDepthModel"; cfg.MODEL.DEPTH_NET.ENCODER_NAME = "18"; cfg.MODEL.DEVICE = dev
+    cfg = get_project_cfg("MonoDepth2"); cfg.MODEL.META_ARCHITECTURE = "SupDepthModel"; cfg.MODEL.DEPTH_NET.ENCODER_NAME = "18"; cfg.MODEL.DEVICE = dev
+    cfg.TEST.GT_SCALE = False
     model = build_model(cfg); model.load_state_dict(OM.init_state_dict(18, seed=31), strict=True); model.train()
     g = np.random.default_rng(3)
     loader = []
@@ -185,12 +186,12 @@ def test_depth_saver_writes_the_reference_png_format(tmp_path):
     """CPU tensors suffice here: the saver's restore is an index gather.  16-bit PNG of depth * 255, truncated (file_utils.py:L5-8), named
     <date>_<drive>_<img_id>.png, restored to the original size through the Resize index maps."""
     from PIL import Image
-    from simpledepthestimation_amd.config import get_cfg
+    from simpledepthestimation_amd.config import get_project_cfg
     from simpledepthestimation_amd.evaluation import EVALUATOR_REGISTRY
     rng = np.random.default_rng(0)
     pred = (rng.random((2, 1, 24, 80)) * 80).astype(np.float32)
     metas = [{"date": "2011_09_26", "drive": "0002", "img_id": f"{i:010d}", "h_before_resize": 37, "w_before_resize": 124} for i in range(2)]
-    saver = EVALUATOR_REGISTRY.get("kitti_depth_saver")(get_cfg(), str(tmp_path / "out"))
+    saver = EVALUATOR_REGISTRY.get("kitti_depth_saver")(get_project_cfg("MonoDepth2"), str(tmp_path / "out"))
     saver.process({"metadata": metas}, {"depth_pred": torch.from_numpy(pred)})
     assert saver.evaluate() is None
     assert sorted(os.listdir(tmp_path / "out")) == ["2011_09_26_0002_0000000000.png", "2011_09_26_0002_0000000001.png"]

@@ -16,8 +16,8 @@ dev = "cuda"
 
 
 def make_cfg(arch, enc, dtype="fp32"):
-    from simpledepthestimation_amd.config import get_cfg
-    cfg = get_cfg()
+    from simpledepthestimation_amd.config import get_project_cfg
+    cfg = get_project_cfg("Supervised" if arch == "SupDepthModel" else "MonoDepth2")
     cfg.MODEL.META_ARCHITECTURE = arch
     if str(enc).startswith("packnet"):           # "packnet1A" / "packnet1B": projects/MonoDepth2/configs/packnet_1a.yaml
         cfg.MODEL.DEPTH_NET.NAME = "PackNet01"
@@ -131,6 +131,29 @@ def test_monodepth2_vs_reference_golden(mod, tag, H, W):
             b2["pose_net_input"] = torch.cat([b2["img"]] + b2["ctx_img"], 1)
             poses = model.pose_net(b2)["pose_pred"]
         assert rel(poses[0], mod.t("mono18.pose0")) < 1e-5 and rel(poses[1], mod.t("mono18.pose1")) < 1e-5
+
+
+def test_monodepth2_resnet50_vs_reference_golden(mono50):
+    """BASELINE.json configs[3] (projects/MonoDepth2/configs/resnet50.yaml): MonoDepth2Model + ResNet-50 encoder through build_model on the HIP
+    path (fp32) vs losses / gradient norms / eval-mode depth produced by the REFERENCE (tests/golden/mono50.npz, oracle/gen_golden.py)."""
+    tag = "mono50"
+    sd = OM.init_state_dict(50, with_pose=True, seed=57)
+    model = build("MonoDepth2Model", 50, sd).train()
+    batch = mono_batch(1, 64, 192, 23)
+    out = model(clone_batch(batch))
+    assert set(k for k in out if "loss" in k) == {"rec_loss", "smooth_loss"}
+    assert abs(out["rec_loss"].item() - float(mono50[f"{tag}.rec_loss"])) < 5e-5 * float(mono50[f"{tag}.rec_loss"])
+    assert abs(out["smooth_loss"].item() - float(mono50[f"{tag}.smooth_loss"])) < 5e-4 * float(mono50[f"{tag}.smooth_loss"])
+    (out["rec_loss"] + out["smooth_loss"]).backward()
+    named = dict(model.named_parameters())
+    for k in [k for k in mono50.keys() if k.startswith(f"{tag}.gnorm.")]:
+        n = k[len(tag) + 7:]
+        g = named[n].grad.norm().item()
+        assert abs(g - float(mono50[k])) < 1e-2 * float(mono50[k]) + 1e-8, f"grad norm of {n}: {g} vs {float(mono50[k])}"
+    model.eval()
+    with torch.no_grad():
+        d = model(clone_batch(batch))["depth_pred"]
+    assert max_rel(d, mono50.t(f"{tag}.eval_depth")) < 1e-4        # north_star: depth maps within 1e-4 relative (fp32)
 
 
 def test_monodepth2_eval_and_options():
@@ -413,6 +436,8 @@ def test_training_loop_schedules_checkpoints_evaluates_and_resumes(tmp_path, arc
     def cfg_for(out, epochs):
         cfg = make_cfg(arch, 18)
         cfg.OUTPUT_DIR = str(out); cfg.LOG_PERIOD = 2; cfg.SOLVER.MAX_EPOCHS = epochs; cfg.SOLVER.LR_STEPS = (1,); cfg.TEST.EVAL_PERIOD = 1
+        cfg.DATASETS.TEST.PREPROCESS = [{"NAME": "LoadImg"}, {"NAME": "Resize", "IMG_W": 192, "IMG_H": 64}, {"NAME": "ToTensor"}]   # the test loader's metadata
+        cfg.TEST.GT_SCALE = False
         return cfg
 
     sd = OM.init_state_dict(18, with_pose=not sup, seed=33)
@@ -440,3 +465,31 @@ def test_training_loop_schedules_checkpoints_evaluates_and_resumes(tmp_path, arc
     assert [r["iteration"] for r in rec2] == [5] and rec2[0]["lr"] == rec[2]["lr"]
     for (k, a), (_, b) in zip(full.module.state_dict().items(), resumed.module.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_graph_step_takes_the_collate_batch_dicts(tmp_path):
+    """The batch dicts of data/datasets/kitti_v2.py:L196-221 through do_train with the hipGraph step: ctx_img / ctx_img_orig as lists of NUMPY
+    arrays, `flip` as one python bool that changes from batch to batch (RandomFlip is in both projects' Base.yaml), `metadata` as a list of
+    dicts.  Each flip value gets its own captured graph set; the run must equal the eager run bit for bit."""
+    import numpy as np
+    from simpledepthestimation_amd.engine.loops import do_train
+    from simpledepthestimation_amd.layers.fakeDDP import FakeDDP
+
+    def collated(seed, flip):
+        b = mono_batch(2, 64, 192, seed)
+        b["ctx_img"] = [t.numpy() for t in b["ctx_img"]]
+        b["ctx_img_orig"] = [t.numpy() for t in b["ctx_img_orig"]]
+        b["flip"] = flip
+        b["metadata"] = [{"date": "2011_09_26", "drive": "0001", "img_id": f"{seed:010d}"}] * 2
+        return b
+    loader = [collated(70, False), collated(71, True), collated(72, True), collated(73, False)]
+    finals = []
+    for use_graph in (True, False):
+        cfg = make_cfg("MonoDepth2Model", 18)
+        cfg.OUTPUT_DIR = str(tmp_path / ("g" if use_graph else "e")); cfg.LOG_PERIOD = 2; cfg.SOLVER.MAX_EPOCHS = 2; cfg.TEST.EVAL_PERIOD = 0
+        model = FakeDDP(build("MonoDepth2Model", 18, OM.init_state_dict(18, with_pose=True, seed=35)))
+        rec = do_train(cfg, model, loader, None, use_graph=use_graph)
+        assert [r["iteration"] for r in rec] == [2, 4, 6, 8] and all(np.isfinite(r["total_loss"]) for r in rec)
+        finals.append({k: v.detach().clone() for k, v in model.module.state_dict().items()})
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k

@@ -401,8 +401,8 @@ def test_adam_step(NN, decoupled):
     groups = [{"params": [pa], "lr": 2e-4, "weight_decay": 1e-2 if decoupled else 0.0}, {"params": [pb], "lr": 1e-4, "weight_decay": 0.0}]
     opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)(groups, eps=1e-6)
     pd, m, v = p.clone().to(dev), torch.zeros(n1 + n2, device=dev), torch.zeros(n1 + n2, device=dev)
-    seg_end = torch.tensor([n1, n1 + n2], dtype=torch.long, device=dev)
-    seg_lr = torch.tensor([2e-4, 1e-4], device=dev); seg_wd = torch.tensor([1e-2 if decoupled else 0.0, 0.0], device=dev)
+    seg_end = [n1, n1 + n2]
+    seg_lr = [2e-4, 1e-4]; seg_wd = [1e-2 if decoupled else 0.0, 0.0]
     for t in range(1, 4):
         gt = gr * (1.0 + 0.1 * t)
         pa.grad, pb.grad = gt[:n1].clone(), gt[n1:].clone()

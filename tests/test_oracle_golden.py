@@ -154,6 +154,20 @@ def test_monodepth2_model(mod, tag, H, W):
         close(G.pose_vec2mat(vec[:, 1]), mod.t("mono18.pose1"), 1e-5, 1e-7)
 
 
+def test_monodepth2_resnet50_model(mono50):
+    """BASELINE.json configs[3] (projects/MonoDepth2/configs/resnet50.yaml): MonoDepth2Model + ResNet-50 encoder vs the reference."""
+    tag = "mono50"
+    sd = _leaf(OM.init_state_dict(50, with_pose=True, seed=57))
+    batch = mono_batch(1, 64, 192, 23)
+    out = OM.monodepth2_forward(sd, batch, 50)
+    close(out["rec_loss"], mono50[f"{tag}.rec_loss"], 2e-5)
+    close(out["smooth_loss"], mono50[f"{tag}.smooth_loss"], 2e-4)
+    names = [k[len(tag) + 7:] for k in mono50.keys() if k.startswith(f"{tag}.gnorm.")]
+    gn = _grad_norms(sd, out["rec_loss"] + out["smooth_loss"], names)
+    for n in names:
+        close(gn[n], mono50[f"{tag}.gnorm.{n}"], 5e-3, 1e-8)
+
+
 @pytest.mark.parametrize("version", ["A", "B"])
 def test_packnet_model(pack, version):
     """MonoDepth2Model + PackNet01 (packnet_1a.yaml with VAR_LOSS_WEIGHT 1e-4; 1B = the channel-addition variant) vs the reference."""
