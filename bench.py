@@ -279,6 +279,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-overlap", action="store_true", help="use the two-phase backward (all-reduce overlap path) even on one GPU")
+    ap.add_argument("--no-side-stream", action="store_true", help="weight-gradient GEMMs on the main stream (single-stream graph: profiling aid)")
+    ap.add_argument("--no-pgemm", action="store_true", help="register-staged GEMM kernels only (A/B against the persistent LDS-DMA GEMM)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -301,6 +303,12 @@ def main():
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
+    if args.no_side_stream or args.no_pgemm:
+        from simpledepthestimation_amd.hip import lib as L, nn as HN
+        if args.no_side_stream:
+            L.SIDE_STREAM = False
+        if args.no_pgemm:
+            HN.set_option(HN.OPT_PGEMM, 0)
     cfg, model, trainer = build(args, device)
     batch = synth_batch(WORKLOADS[args.workload]["arch"], args.batch, args.height, args.width, 1000 + rank, device)
 

@@ -166,12 +166,14 @@ int sde_conv_set_halo_min_blocks(int min_blocks);
 /* Dispatcher options (process-wide; A/B measurements and tests): returns the previous value, negative on a bad key / value.  Results do
  * not depend on them beyond fp32 summation order.
  *   SDE_OPT_PGEMM        1 (default): layers with 64-channel-multiple inputs run on the persistent LDS-DMA GEMM (csrc/pgemm.hip); 0: never
- *   SDE_OPT_PGEMM_DEPTH  stages of its LDS ring: 3 or 4 (default 4)
+ *   SDE_OPT_PGEMM_DEPTH  stages of its LDS ring: 3 (default) or 4
  *   SDE_OPT_PGEMM_3X3    1: it also takes the 3x3 stride-1 layers the LDS-halo kernel would get (default 0) */
 #define SDE_OPT_PGEMM 1
 #define SDE_OPT_PGEMM_DEPTH 2
 #define SDE_OPT_PGEMM_3X3 3
-#define SDE_OPT_PGEMM_TILE 4 /* force its tile: 64064, 128064, 128128; 0 (default) = chosen per layer */
+#define SDE_OPT_PGEMM_TILE 4   /* force its tile: 64064, 128064, 128128; 0 (default) = chosen per layer */
+#define SDE_OPT_SPLITK 5       /* 1 (default): small-M, long-K layers cut K into up to 8 ranges (sde_conv_fwd_ws); 0: never */
+#define SDE_OPT_WGRAD_BLOCKS 6 /* workgroup target of the weight-gradient GEMM's pixel splits (default 256 = one per CU) */
 int sde_conv_set_option(int key, int value);
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).

@@ -2,7 +2,7 @@
 mkdir -p gpurun_out/prof
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-export SDE_WGRAD_SIDE_STREAM=0; timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -o gaps -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --profile-steps 0 > gpurun_out/prof/gaps_bench.json 2> gpurun_out/prof/gaps_bench.err
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -o gaps -- python3 bench.py --no-side-stream --steps 6 --warmup 3 --no-cpu-baseline --profile-steps 0 > gpurun_out/prof/gaps_bench.json 2> gpurun_out/prof/gaps_bench.err
 echo "rc=$?"; tail -c 200 gpurun_out/prof/gaps_bench.json
 python3 - <<'PY'
 import csv, glob, collections

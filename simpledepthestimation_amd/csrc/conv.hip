@@ -1111,14 +1111,11 @@ int launch_igemm(const IGemmP& p, hipStream_t s) {
 // Tile choice (one place): returns BM*1000 + BN.  Small-N layers get narrow N tiles (the GEMM is then A-bandwidth bound);
 // layers whose 128x128 grid would not fill the 256 CUs fall back to 64x64 tiles.
 int pick_tile(long M, int N, int Ktot) {
-    // Measured end to end (Supervised R50, bs 12): 64x64 tiles for every N > 64 layer 10.10 ms/step, 128x64 10.28, 128x128 10.47.
-    // The loop is latency-bound, not MFMA-bound: the 64x64 kernel needs 111 VGPRs and 32 KB of LDS (4 workgroups per CU), the 128x128
-    // one 222 VGPRs and 70 KB (2 per CU), and occupancy wins over operand reuse.  SDE_TILE_BIG / SDE_TILE_MID re-open the choice.
-    static const int big = [] { const char* e = getenv("SDE_TILE_BIG"); return e ? atoi(e) : 64064; }();       // N > 64:  64064 | 128064 | 128128
-    static const int mid = [] { const char* e = getenv("SDE_TILE_MID"); return e ? atoi(e) : 64064; }();       // 32 < N <= 64: 128064 | 64064
-    (void)Ktot;
-    if (N > 64) return big;
-    if (N > 32) return (sde_cdiv(M, 128) < 192) ? 64064 : mid;
+    // Measured end to end in round 1 (Supervised R50, bs 12): 64x64 tiles for every N > 32 layer 10.10 ms/step, 128x64 10.28, 128x128 10.47 -- the
+    // register-staged loop is latency-bound, not MFMA-bound (111 VGPRs / 32 KB LDS = 4 workgroups per CU vs 222 / 70 KB = 2), so occupancy wins
+    // over operand reuse.  The wide instantiations were removed with their switches.
+    (void)M; (void)Ktot;
+    if (N > 32) return 64064;
     if (N > 16) return 128032;
     return 128016;
 }
@@ -1153,16 +1150,13 @@ int dispatch_src(const IGemmP& p, hipStream_t s) {
 int g_halo_min_blocks = 192;      // below this many workgroups the 64x64 generic tiles fill the chip better (sde_conv_set_halo_min_blocks)
 
 long halo_tiles(const Gather& g) { return (long)g.Bn * sde_cdiv(g.OH, HT_H) * sde_cdiv(g.OW, HT_W); }
-// N tile of the halo kernel: 128 wide when that still gives >= 256 workgroups, else 64 (mid-resolution layers), 32 / 16 for narrow outputs
+// N tile of the halo kernel: 64, or 32 / 16 for narrow outputs
 int halo_bn(const Gather& g, int ldy) {
-    static const int bn_max = [] { const char* e = getenv("SDE_HALO_BN_MAX"); return e ? atoi(e) : 64; }();      // 64: narrower tile, 3 waves / SIMD (measured 10.05 vs 10.10 ms/step); 128 re-opens the wide tile
-    if (ldy > 64) return (bn_max >= 128 && halo_tiles(g) * sde_cdiv(ldy, 128) >= 256) ? 128 : 64;
-    return ldy > 32 ? 64 : (ldy > 16 ? 32 : 16);
+    (void)g;
+    return ldy > 32 ? 64 : (ldy > 16 ? 32 : 16);      // 64 wide at most: 3 waves / SIMD (measured 10.05 vs 10.10 ms/step against a 128-wide tile)
 }
 bool use_halo(const Gather& g, int dtype, int ldy) {
-    static const int off = [] { const char* e = getenv("SDE_NO_HALO"); return e ? atoi(e) : 0; }();
-    static const int min_n = [] { const char* e = getenv("SDE_HALO_MIN_N"); return e ? atoi(e) : 0; }();
-    if (off || ldy < min_n || g_halo_min_blocks < 0 || dtype != SDE_BF16 || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.mode == SDE_SRC_ZEROINS) return false;
+    if (g_halo_min_blocks < 0 || dtype != SDE_BF16 || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.mode == SDE_SRC_ZEROINS) return false;
     if (g.mode == SDE_SRC_UPCAT && !g.reflect) return false;
     if (g.Cin % 8 || g.OH < HT_H || g.OW < HT_W) return false;
     if (sde_cdiv(g.Cin, 64) * 64 * 3 > g.Cin * 4) return false;     // the tile stages 64-channel blocks: narrow inputs (Cin < 48) waste MFMA and LDS
@@ -1194,7 +1188,6 @@ int dispatch_halo_src(const IGemmP& p, hipStream_t s) {
 }
 int dispatch_halo(const IGemmP& p, hipStream_t s) {
     switch (halo_bn(p.g, p.ldy)) {
-        case 128: return dispatch_halo_src<128, 2, 2>(p, s);
         case 64: return dispatch_halo_src<64, 2, 2>(p, s);
         case 32: return dispatch_halo_src<32, 4, 1>(p, s);
         default: return dispatch_halo_src<16, 4, 1>(p, s);
@@ -1204,8 +1197,6 @@ int dispatch_halo(const IGemmP& p, hipStream_t s) {
 template <typename T>
 int dispatch_igemm(const IGemmP& p, hipStream_t s) {
     switch (pick_tile(p.g.M, p.ldy, p.g.Ktot)) {
-        case 128128: return dispatch_src<T, 128, 128, 2, 2>(p, s);
-        case 128064: return dispatch_src<T, 128, 64, 2, 2>(p, s);
         case 128032: return dispatch_src<T, 128, 32, 4, 1>(p, s);
         case 128016: return dispatch_src<T, 128, 16, 4, 1>(p, s);
         default: return dispatch_src<T, 64, 64, 2, 2>(p, s);
@@ -1241,23 +1232,14 @@ int dispatch_wsrc(const WGradP& p, int splits, hipStream_t s) {
     }
 }
 
-int wgrad_bng() {       // K-tile width of the weight-gradient GEMM for Cout >= 64 layers: 128, or 64 (experiment: SDE_WGRAD_BNG=64)
-    static const int v = [] { const char* e = getenv("SDE_WGRAD_BNG"); return (e && atoi(e) == 64) ? 64 : 128; }();
-    return v;
-}
-int wgrad_bmg(int Cout) {
-    // 64 x 128 (Cout x K) tiles by default: twice the tiles of 128 x 128, so half the pixel splits / fp32 slabs for the same number of
-    // workgroups (measured 10.03 vs 10.12 ms/step); SDE_WGRAD_BMG=128 restores the wide tile
-    static const int cap = [] { const char* e = getenv("SDE_WGRAD_BMG"); const int v = e ? atoi(e) : 0; return v == 128 ? 128 : 64; }();
-    const int b = Cout > 64 ? 128 : (Cout > 32 ? 64 : (Cout > 16 ? 32 : 16));
-    return b > cap ? cap : b;
-}
+// Weight-gradient tiles (Cout x K): 64 x 128 -- twice the tiles of 128 x 128, so half the pixel splits / fp32 slabs for the same number of
+// workgroups (measured 10.03 vs 10.12 ms/step; 64 x 64 measured neutral) -- and 32 / 16 rows for narrow outputs.
+int wgrad_bmg(int Cout) { return Cout > 32 ? 64 : (Cout > 16 ? 32 : 16); }
 
 template <typename T>
 int dispatch_wgrad(const WGradP& p, int splits, hipStream_t s) {
     switch (wgrad_bmg(p.Cout)) {
-        case 128: return dispatch_wsrc<T, 128, 128, 2, 2>(p, splits, s);
-        case 64: return wgrad_bng() == 64 ? dispatch_wsrc<T, 64, 64, 2, 2>(p, splits, s) : dispatch_wsrc<T, 64, 128, 1, 4>(p, splits, s);
+        case 64: return dispatch_wsrc<T, 64, 128, 1, 4>(p, splits, s);
         case 32: return dispatch_wsrc<T, 32, 128, 1, 4>(p, splits, s);
         default: return dispatch_wsrc<T, 16, 128, 1, 4>(p, splits, s);
     }
@@ -1296,9 +1278,13 @@ int pgemm_run(const IGemmP& p, int depth, hipStream_t s);
 extern int g_pgemm_force_tile;
 }
 namespace {
-int g_use_pgemm = 1;        // sde_conv_set_option(SDE_OPT_PGEMM, 0/1)
-int g_pgemm_depth = 4;      // sde_conv_set_option(SDE_OPT_PGEMM_DEPTH, 3/4): ring stages
-int g_pgemm_3x3 = 0;        // sde_conv_set_option(SDE_OPT_PGEMM_3X3, 1): also take the layers the LDS-halo 3x3 kernel would get
+// Dispatcher options: the ONLY process-wide state of the convolution engine (sde_conv_set_option; every former SDE_* environment switch of
+// this file either became one of these or was deleted with the code path it selected).
+int g_use_pgemm = 1;        // SDE_OPT_PGEMM
+int g_pgemm_depth = 3;      // SDE_OPT_PGEMM_DEPTH: ring stages (3: 48 KB -> 3 workgroups per CU; measured better than 4 on every layer)
+int g_pgemm_3x3 = 0;        // SDE_OPT_PGEMM_3X3: also take the layers the LDS-halo 3x3 kernel would get
+int g_splitk = 1;           // SDE_OPT_SPLITK
+long g_wgrad_blocks = 256;  // SDE_OPT_WGRAD_BLOCKS
 bool use_pgemm(const Gather& g, int dtype, int ldy) {
     if (!g_use_pgemm || !pgemm_applicable(g, dtype, ldy)) return false;
     return g_pgemm_3x3 || !use_halo(g, dtype, ldy);
@@ -1310,14 +1296,15 @@ extern "C" {
 // Split-K factor of a forward / data-gradient GEMM: layers whose 64x64 tiling leaves most of the 256 CUs x 4 workgroup slots empty while
 // the K loop is long (layer4 and the first decoder levels: M = 1440 ... 5760 pixels) cut K into up to 8 ranges.
 static int pick_ksplit(const Gather& g, int dtype, int ldy) {
-    static const int off = [] { const char* e = getenv("SDE_NO_SPLITK"); return e ? atoi(e) : 0; }();
     const bool pg = use_pgemm(g, dtype, ldy);
-    if (pg && pgemm_tile(g.M, ldy) != 64064) return 1;
-    if (off || (!pg && use_halo(g, dtype, ldy)) || pick_tile(g.M, ldy, g.Ktot) != 64064 || ldy % 4) return 1;
+    if (!g_splitk || ldy % 4) return 1;
+    if (pg ? pgemm_tile(g.M, ldy) != 64064 : (use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064)) return 1;
     const long tiles = (long)sde_cdiv(g.M, 64) * sde_cdiv(ldy, 64);
     const int nk = sde_cdiv(g.Ktot, dtype == SDE_BF16 ? 64 : 32);
-    static const long tmax = [] { const char* e = getenv("SDE_SPLITK_TILES"); return e ? atol(e) : 384L; }();      // split when fewer tiles than this ...
-    static const long target = [] { const char* e = getenv("SDE_SPLITK_TARGET"); return e ? atol(e) : 768L; }();  // ... aiming at this many workgroups
+    // register-staged kernel (4 workgroups per CU, pipeline drained per tile): split below 384 tiles towards 768 workgroups (measured 10.12 ->
+    // 9.73 ms/step, flat between 256 and 1024).  Persistent LDS-DMA kernel: only below one tile per CU (256), towards 512 -- the M = 5760
+    // layers (360 tiles) measured 11-22 us unsplit against 18-28 us split three ways (profiles/r02_gemm_microbench.txt).
+    const long tmax = pg ? 256 : 384, target = pg ? 512 : 768;
     if (tiles >= tmax || nk < 16) return 1;
     long S = sde_cdiv(target, tiles);
     if (S > 8) S = 8;
@@ -1335,8 +1322,7 @@ static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const flo
     SDE_CHECK_ARG(act == SDE_ACT_NONE || act == SDE_ACT_ELU, "sde_conv_fwd: bad act %d", act);
     p.w = w_packed; p.bias = bias; p.y = y; p.stats = stats; p.Cout = Cout; p.ldy = ldy; p.act = act;
     p.ksplit = 1; p.ws = nullptr;
-    static const int no_kfull = [] { const char* e = getenv("SDE_NO_KFULL"); return e ? atoi(e) : 0; }();
-    p.no_kfull = no_kfull;
+    p.no_kfull = 0;
     const int S = ws ? pick_ksplit(p.g, d->dtype, ldy) : 1;
     if (S > 1) {
         SDE_CHECK_ARG(ws_bytes >= (size_t)S * p.g.M * ldy * sizeof(float), "sde_conv_fwd_ws: workspace too small (%zu bytes)", ws_bytes);
@@ -1396,14 +1382,9 @@ int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
 int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     const long M = (long)d->Bn * d->OH * d->OW;
     const int Ktot = d->KH * d->KW * (d->C0 + d->C1);
-    const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, wgrad_bmg(Cout) == 64 ? wgrad_bng() : 128);
+    const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, 128);
     const int BR = d->dtype == SDE_BF16 ? 64 : 32;
-    static const long target = [] { const char* e = getenv("SDE_WGRAD_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 256L; }();
-    // layers whose slab is tiny (few output channels x few K columns) but whose pixel count is huge -- the full-resolution decoder tail -- are
-    // pure loader latency at one workgroup per CU; extra splits cost them almost nothing in slab traffic (SDE_WGRAD_SMALL_MULT x the target)
-    static const long small_kb = [] { const char* e = getenv("SDE_WGRAD_SMALL_KB"); const long v = e ? atol(e) : 0; return v > 0 ? v : 128L; }();
-    static const long small_mult = [] { const char* e = getenv("SDE_WGRAD_SMALL_MULT"); const long v = e ? atol(e) : 0; return v > 0 ? v : 1L; }();
-    const long tgt = ((long)Cout * Ktot * 4 <= (small_kb << 10) && M >= (1L << 18)) ? target * small_mult : target;
+    const long tgt = g_wgrad_blocks;            // default 256 = one workgroup per CU (sde_conv_set_option(SDE_OPT_WGRAD_BLOCKS, n))
     long want = (tgt + tiles - 1) / tiles;                  // default 256 (one workgroup per CU): measured best end to end -- every extra split is another fp32 slab through HBM
     const long max_by_rows = (M + 4 * BR - 1) / (4 * BR);   // at least 4 stages per split
     if (want > max_by_rows) want = max_by_rows;
@@ -1426,8 +1407,7 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     rps = sde_cdiv(rps, BR) * BR;
     SDE_CHECK_ARG((long)rps * splits >= p.g.M, "sde_conv_wgrad: split arithmetic");
     p.dy = dy; p.slab = slab; p.Cout = Cout; p.ldd = ldd; p.rows_per_split = rps;
-    static const int sb = [] { const char* e = getenv("SDE_WGRAD_SINGLE_BUF"); return e ? atoi(e) : 1; }();      // measured -0.7 % step time
-    p.single_buf = (sb && d->dtype == SDE_BF16 && wgrad_bmg(Cout) <= 64) ? 1 : 0;
+    p.single_buf = d->dtype == SDE_BF16 ? 1 : 0;      // one LDS stage buffer for the 16-bit tiles: 3 workgroups per CU, measured -0.7 % step time
     if (d->dtype == SDE_BF16) dispatch_wgrad<bf16_t>(p, splits, s);
     else dispatch_wgrad<float>(p, splits, s);
     SDE_CHECK_LAUNCH("sde_conv_wgrad");
@@ -1511,7 +1491,14 @@ int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int
 }
 
 int sde_conv_set_option(int key, int value) {
-    int* slot = key == SDE_OPT_PGEMM ? &g_use_pgemm : key == SDE_OPT_PGEMM_DEPTH ? &g_pgemm_depth : key == SDE_OPT_PGEMM_3X3 ? &g_pgemm_3x3 : key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : nullptr;
+    if (key == SDE_OPT_WGRAD_BLOCKS) {
+        SDE_CHECK_ARG(value >= 1 && value <= 65536, "sde_conv_set_option: bad workgroup target %d", value);
+        const int old = (int)g_wgrad_blocks;
+        g_wgrad_blocks = value;
+        return old;
+    }
+    int* slot = key == SDE_OPT_PGEMM ? &g_use_pgemm : key == SDE_OPT_PGEMM_DEPTH ? &g_pgemm_depth : key == SDE_OPT_PGEMM_3X3 ? &g_pgemm_3x3 :
+                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : nullptr;
     SDE_CHECK_ARG(slot, "sde_conv_set_option: unknown key %d", key);
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_DEPTH || value == 3 || value == 4, "sde_conv_set_option: ring depth must be 3 or 4");
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_TILE || value == 0 || value == 64064 || value == 128064 || value == 128128, "sde_conv_set_option: bad tile %d", value);

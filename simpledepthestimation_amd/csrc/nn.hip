@@ -898,7 +898,7 @@ __global__ void loss_scale_update_kernel(float* __restrict__ state, float growth
 const float* pre_reduce(const float* part, int& rows, int width, hipStream_t s) {
     // the finalize kernels read rows with 32 independent lanes, so slabs up to SDE_PRE_REDUCE_ROWS rows (default 512: 16 loads per lane) need
     // no extra launch; 2048 measured slower (the 64 serial loads per lane cost more than the extra launch)
-    static const int thr = [] { const char* e = getenv("SDE_PRE_REDUCE_ROWS"); return e ? atoi(e) : 512; }();
+    constexpr int thr = 512;
     if (rows <= thr) return part;
     float* out = const_cast<float*>(part) + (size_t)rows * width;
     const int chunk = (rows + SDE_REDUCE_ROWS - 1) / SDE_REDUCE_ROWS;
@@ -969,7 +969,7 @@ int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu
 
 int sde_reduce_num_blocks(long M, int C) {
     // ~4 sixteen-byte groups per thread (bf16 grouping), enough workgroups to keep HBM busy: these passes are pure streaming
-    static const long cap = [] { const char* e = getenv("SDE_REDUCE_MAX_BLOCKS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 2048L; }();
+    constexpr long cap = 2048;
     long nb = (M * (long)C / 8 + 1023) / 1024;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;

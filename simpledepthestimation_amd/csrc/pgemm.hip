@@ -395,13 +395,14 @@ int pgemm_src_kind(const Gather& g) {
     return g.reflect ? SRC_PLAIN_REFLECT : SRC_PLAIN_ZERO;
 }
 
-// Tile choice (one place): BM*1000 + BN.  128-pixel tiles once they still give two work items per CU.
+// Tile choice (one place): BM*1000 + BN.  Measured on every layer shape of the ResNet-50 / ResNet-18 workloads (profiles/r02_gemm_microbench.txt):
+// 64x64 with a 3-stage ring (3 workgroups per CU) is the fastest or within 3 % of it everywhere; 128x64 (2 per CU) loses 5-40 %, 128x128
+// (4 waves, 236 VGPRs, one workgroup per CU) runs 1.5-2x slower -- at this network's sizes the tiles are bound by how many loads a CU keeps
+// in flight, not by operand reuse.  The larger instantiations stay reachable through SDE_OPT_PGEMM_TILE for measurements.
 int g_pgemm_force_tile = 0;     // sde_conv_set_option(SDE_OPT_PGEMM_TILE, 64064 | 128064 | 128128 | 0 = automatic)
 int pgemm_tile(long M, int ldy) {
-    if (g_pgemm_force_tile) return g_pgemm_force_tile;
-    if (ldy > 64 && (long)sde_cdiv(M, 128) * sde_cdiv(ldy, 128) >= 512) return 128128;
-    if ((long)sde_cdiv(M, 128) * sde_cdiv(ldy, 64) >= 512) return 128064;
-    return 64064;
+    (void)M; (void)ldy;
+    return g_pgemm_force_tile ? g_pgemm_force_tile : 64064;
 }
 
 int pgemm_run(const IGemmP& p, int depth, hipStream_t s) {

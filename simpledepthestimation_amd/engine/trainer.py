@@ -122,8 +122,8 @@ class HipTrainer:
         self._static_out = None
         self._packer = None            # built lazily after the first eager step (needs the operand shapes seen in forward)
         self.batch_pack = adam_fn is None
-        # one weight-gradient slab reduction launch per backward phase (SDE_DEFER_WGRAD=0: per-layer reductions on the side stream instead)
-        self._wreduce = HN.WGradReducer() if (adam_fn is None and os.environ.get("SDE_DEFER_WGRAD", "1") != "0") else None
+        # one weight-gradient slab reduction launch per backward phase
+        self._wreduce = HN.WGradReducer() if adam_fn is None else None
 
     # ------------------------------------------------------------------------------------------------------------
     def set_lr(self, lrs):

@@ -111,38 +111,23 @@ def stream():
 
 
 _side = {}
-SIDE_STREAM = os.environ.get("SDE_WGRAD_SIDE_STREAM", "1") != "0"
-# SDE_LATE_JOIN=1 joins the side stream once per backward phase (at the reducer's flush) instead of after every layer.  Measured WORSE
-# (10.39 vs 9.69 ms/step, Supervised R50): operands kept alive for the lagging GEMMs stop the allocator from recycling hot blocks, and the
-# step's working set falls out of the 256 MB Infinity Cache.  Off by default; kept as an experiment knob.
-LATE_JOIN = os.environ.get("SDE_LATE_JOIN", "0") == "1"
-# Join a layer's weight-gradient GEMM (side stream) this many convolutions later instead of at the end of its own backward: the main stream
-# runs on into the next layers' BatchNorm / data-gradient work instead of idling at the per-layer join (measured, ms/step: lag 0 9.54,
-# 1 9.20, 2 9.01, 3 9.10, 5 9.21); operands of the lagging layers are held alive, so the working set grows by that many layers only.
-JOIN_LAG = int(os.environ.get("SDE_JOIN_LAG", "2"))
-# > 1: the weight-gradient GEMMs of that many consecutive layers are launched behind ONE fork of the side stream (fewer cross-stream edges in the
-# captured graph: a trace of the replayed graph shows the GPU 99.5 % busy without the side stream and 90 % with a fork + join per layer)
-# (measured, Supervised R50 ms/step: group 1 9.22, 2 8.85, 3 8.84, 4 8.91, 6 8.90; MonoDepth2-R18 6.52 -> 6.33)
-WGRAD_GROUP = int(os.environ.get("SDE_WGRAD_GROUP", "3"))
-GROUP_MAX_BYTES = int(float(os.environ.get("SDE_WGRAD_GROUP_MAX_MB", "128")) * (1 << 20))     # layers with more operand bytes than this fork alone
-PACK_SPLIT = os.environ.get("SDE_PACK_SPLIT", "0") == "1"          # pack the data-gradient operands on the side stream during the forward pass
-DEFER_MAX_BYTES = int(float(os.environ.get("SDE_DEFER_MAX_MB", "2")) * (1 << 20))     # weight-gradient slab stacks up to this size join the batched reduction
-
-
-N_SIDE = max(1, int(os.environ.get("SDE_SIDE_STREAMS", "1")))      # weight-gradient GEMMs of consecutive layers alternate over this many streams
-_side_rr = [0]
+# Weight-gradient GEMMs run on ONE side stream, forked in groups and joined late (hip/nn.py: _Conv2d.backward, WGradReducer).  The values below
+# were each decided by an A/B run inside one gpurun call in round 1 (DESIGN.md 6.1 keeps the measurements); the environment switches that
+# selected the losing variants (late join per phase, several side streams, packing on the side stream) were removed with those variants.
+SIDE_STREAM = True      # HipTrainer(side_stream=False) / hip.lib.SIDE_STREAM = False: single-stream backward (profiling, debugging)
+JOIN_LAG = 2            # the main stream joins a group's GEMMs that many convolutions later (0: 9.54, 1: 9.20, 2: 9.01, 3: 9.10 ms/step)
+WGRAD_GROUP = 3         # weight-gradient GEMMs of that many consecutive layers behind one fork (1: 9.22, 2: 8.85, 3: 8.84, 4: 8.91 ms/step)
+GROUP_MAX_BYTES = 128 << 20     # layers with more operand bytes fork alone (PackNet's 190 MB maps: 57.7 vs 60.2 ms/step)
+DEFER_MAX_BYTES = 2 << 20       # slab stacks up to this size join the phase's batched reduction; bigger ones are summed at once, cache-resident
 
 
 def side_stream(rotate=True):
-    """Per-device helper stream(s): weight-gradient GEMMs run there concurrently with the data-gradient GEMM of the same layer (fork/join
-    with stream / event waits, so they are captured into the step's hipGraph as parallel branches).  With SDE_SIDE_STREAMS > 1 consecutive
-    layers alternate over the streams, so two weight-gradient GEMMs can be in flight at once."""
+    """Per-device helper stream: weight-gradient GEMMs run there concurrently with the data-gradient GEMM of the same layers (fork / join with
+    stream / event waits, so they are captured into the step's hipGraph as a parallel branch)."""
     d = torch.cuda.current_device()
     if d not in _side:
-        _side[d] = [torch.cuda.Stream(device=d) for _ in range(N_SIDE)]
-    if rotate:
-        _side_rr[0] = (_side_rr[0] + 1) % N_SIDE
-    return _side[d][_side_rr[0]]
+        _side[d] = [torch.cuda.Stream(device=d)]
+    return _side[d][0]
 
 
 def all_side_streams():

@@ -62,7 +62,7 @@ L.register_protos({
 })
 
 
-OPT_PGEMM, OPT_PGEMM_DEPTH, OPT_PGEMM_3X3, OPT_PGEMM_TILE = 1, 2, 3, 4      # SDE_OPT_* of include/sde_hip.h
+OPT_PGEMM, OPT_PGEMM_DEPTH, OPT_PGEMM_3X3, OPT_PGEMM_TILE, OPT_SPLITK, OPT_WGRAD_BLOCKS = 1, 2, 3, 4, 5, 6      # SDE_OPT_* of include/sde_hip.h
 
 
 def set_option(key, value):
@@ -249,7 +249,7 @@ class _Conv2d(torch.autograd.Function):
                 # layers with very large operands (PackNet's full-resolution 64-channel maps: 190 MB each) fork on their own: holding three of
                 # them alive for a group pushes the working set out of the Infinity Cache (PackNet-1A: 60.2 vs 58.4 ms/step when grouped)
                 op_bytes = (dz.numel() + x0.numel() + (x1.numel() if x1 is not None else 0)) * dz.element_size()
-                grouped = forked and L.WGRAD_GROUP > 1 and WGRAD_DEFER is not None and not L.LATE_JOIN and op_bytes <= L.GROUP_MAX_BYTES
+                grouped = forked and L.WGRAD_GROUP > 1 and WGRAD_DEFER is not None and op_bytes <= L.GROUP_MAX_BYTES
                 if forked and not grouped and WGRAD_DEFER is not None:
                     WGRAD_DEFER.run_queue()              # keep the side stream in layer order
                 cur = torch.cuda.current_stream()
@@ -305,16 +305,6 @@ class _Conv2d(torch.autograd.Function):
                                    dict(jobs=1))
                     if forked:
                         slab.record_stream(side)
-                # With a deferred reduction the join with the side stream can wait until the reducer's flush: the weight-gradient GEMMs then
-                # run freely behind the data-gradient chain instead of in lock-step with it.  Their operands must outlive this node:
-                # record_stream keeps the blocks from being recycled before the side stream has passed them.
-                late_join = forked and defer is not None and L.LATE_JOIN
-                if late_join:
-                    for t in (dz, x0, x1):
-                        if t is not None:
-                            t.record_stream(side)
-                    defer.forked = True
-                    forked = False
                 if wslot is not None:
                     dw = None
             st["dw"], st["forked"], st["side"] = dw, forked, side
@@ -480,33 +470,16 @@ class WeightPacker:
             arr = (PackItem * len(rows))(*[PackItem(*it) for it in rows])
             return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
         self.items = table(items)
-        # SDE_PACK_SPLIT: the data-gradient operands are not needed before backward -> pack them on the side stream, behind the forward
-        # operands and concurrently with the forward pass (join_dgrad() before backward)
-        self.items_fwd = table([it[:2] + (0,) + it[3:] for it in items])
-        self.items_dgrad = table([it[:1] + (0,) + it[2:] for it in items])
         self.n, self.total = len(items), end
         self._ptrs = [w.data_ptr() for w, _, _ in self._keep]
-        self._forked = False
 
     def run(self):
         if any(w.data_ptr() != p for (w, _, _), p in zip(self._keep, self._ptrs)):
             raise L.SdeHipError("WeightPacker: a weight tensor moved (e.g. flattened after the packer was built); rebuild the packer")
-        lib, dc = L.lib(), dtype_code(self.dtype)
-        if not (L.PACK_SPLIT and L.SIDE_STREAM):
-            L.check(lib.sde_pack_weights_batched(L.ptr(self.items), self.n, self.total, dc, L.stream()), "sde_pack_weights_batched")
-            return
-        L.check(lib.sde_pack_weights_batched(L.ptr(self.items_fwd), self.n, self.total, dc, L.stream()), "sde_pack_weights_batched")
-        cur, side = torch.cuda.current_stream(), L.side_stream(rotate=False)
-        side.wait_stream(cur)                 # after the optimizer step that produced the weights (and after the forward-operand pack)
-        with torch.cuda.stream(side):
-            L.check(lib.sde_pack_weights_batched(L.ptr(self.items_dgrad), self.n, self.total, dc, L.stream()), "sde_pack_weights_batched")
-        self._forked = True
+        L.check(L.lib().sde_pack_weights_batched(L.ptr(self.items), self.n, self.total, dtype_code(self.dtype), L.stream()), "sde_pack_weights_batched")
 
     def join_dgrad(self):
-        """Call before backward: the data-gradient operands packed on the side stream must be complete."""
-        if self._forked:
-            torch.cuda.current_stream().wait_stream(L.side_stream(rotate=False))
-            self._forked = False
+        """Kept for the trainer's call order (the data-gradient operands are packed by the same launch as the forward ones)."""
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, skip=None, upsample=False, bn_stats=False, owner=None):

@@ -49,6 +49,8 @@ CASES = [
     ("upcat_64_0_64", 2, 12, 20, 64, 0, 64, 3, 1, 1, True, True, 1, 7064064),
     ("5x5_64_64", 1, 12, 20, 64, 0, 64, 5, 1, 2, False, True, 0, 7064064),
     ("3x3_64_64_big_t128064", 2, 128, 256, 64, 0, 64, 3, 1, 1, False, False, 0, 7128064),
+    ("3x3_128_256_t128128", 2, 24, 40, 128, 0, 256, 3, 1, 1, False, True, 1, 7128128),
+    ("upcat_64_64_128_t128064", 2, 12, 20, 64, 64, 128, 3, 1, 1, True, True, 1, 7128064),
 ]
 
 
@@ -90,6 +92,7 @@ def test_pgemm_conv(NN, case, depth):
 
     old_depth = NN.set_option(NN.OPT_PGEMM_DEPTH, depth)
     old_3x3 = NN.set_option(NN.OPT_PGEMM_3X3, 1)        # also the layers the LDS-halo kernel would take
+    old_tile = NN.set_option(NN.OPT_PGEMM_TILE, variant - 7000000)      # the dispatcher's own choice is 64x64 everywhere; the larger tiles are forced here
     try:
         outs = {}
         for on in (1, 0):
@@ -114,6 +117,7 @@ def test_pgemm_conv(NN, case, depth):
         NN.set_option(NN.OPT_PGEMM, 1)
         NN.set_option(NN.OPT_PGEMM_DEPTH, old_depth)
         NN.set_option(NN.OPT_PGEMM_3X3, old_3x3)
+        NN.set_option(NN.OPT_PGEMM_TILE, old_tile)
     y1, st1, dx1, ds1 = outs[1]
     y0, st0, dx0, ds0 = outs[0]
     if y1.shape[3] > Cout:
