@@ -30,13 +30,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}    # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}    # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 WORKLOADS = {
     "sup_r50": dict(arch="SupDepthModel", enc="50", desc="Supervised ResNet-50 (BASELINE configs[1])"),
     "sup_r18": dict(arch="SupDepthModel", enc="18", desc="Supervised ResNet-18"),
     "mono_r18": dict(arch="MonoDepth2Model", enc="18", desc="MonoDepth2 ResNet-18 3-frame (BASELINE configs[2])"),
     "mono_r50": dict(arch="MonoDepth2Model", enc="50", desc="MonoDepth2 ResNet-50 3-frame (BASELINE configs[3])"),
-    "mono_packnet": dict(arch="MonoDepth2Model", enc="18", packnet="1A", desc="MonoDepth2 PackNet-1A 3-frame (BASELINE configs[4], bf16 instead of fp16)"),
+    "mono_packnet": dict(arch="MonoDepth2Model", enc="18", packnet="1A", desc="MonoDepth2 PackNet-1A 3-frame (BASELINE configs[4]; --dtype fp16 = its fp16 + loss scaling)"),
 }
 
 
@@ -55,6 +55,7 @@ def build(args, device):
     cfg.MODEL.META_ARCHITECTURE = wl["arch"]
     cfg.MODEL.DEPTH_NET.ENCODER_NAME = wl["enc"]
     cfg.MODEL.COMPUTE_DTYPE = args.dtype
+    cfg.SOLVER.AMP = args.dtype == "fp16"
     cfg.MODEL.DEVICE = str(device)
     if wl.get("packnet"):                           # projects/MonoDepth2/configs/packnet_1a.yaml
         cfg.MODEL.DEPTH_NET.NAME, cfg.MODEL.DEPTH_NET.VERSION, cfg.LOSS.VAR_LOSS_WEIGHT = "PackNet01", wl["packnet"], 1e-4
@@ -137,7 +138,7 @@ def pmc_traffic(dom_key, dtype):
     MI355X_MICROARCH.md prescribes; KB -> bytes).  None when no matching profile is committed (e.g. other dtype / workload)."""
     import csv
     import glob
-    if dtype != "bf16":
+    if dtype == "fp32":
         return None, None
     kind, variant = dom_key
     if kind == "igemm":
@@ -267,7 +268,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="sup_r50", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"], help="fp16 = fp16 storage + dynamic loss scaling (SOLVER.AMP)")
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
@@ -338,7 +339,7 @@ def main():
         value = args.batch * world * args.steps / elapsed
         out = {"metric": "training images/sec at 192x640 bs=12/GPU", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+               "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.dtype], "data": "synthetic",
                "config": {"workload": f"{WORKLOADS[args.workload]['desc']}, {args.dtype} storage / fp32 accumulate, bs={args.batch}/GPU, "
                                       f"{args.height}x{args.width}, fwd+bwd+optimizer, random-init weights", "global_batch": args.batch * world,
                           "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "allreduce_overlap": bool(trainer.overlap)},

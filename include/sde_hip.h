@@ -11,7 +11,7 @@
  *     inside a hipGraph capture.  Work is enqueued on `stream` (a hipStream_t; NULL = default stream).
  *   - return value: 0 = SDE_OK, negative = error (sde_last_error() gives the message). Never throws.
  *   - images are planar NCHW fp32 exactly as the reference's batch dict holds them; network activations
- *     are NHWC (channels-last) in fp32 or bf16, selected by the `dtype` argument (SDE_F32 / SDE_BF16).
+ *     are NHWC (channels-last) in fp32, bf16 or fp16, selected by the `dtype` argument (SDE_F32 / SDE_BF16 / SDE_F16).
  *   - thread safety: stateless and re-entrant given distinct streams/buffers.
  */
 #ifndef SDE_HIP_H
@@ -28,6 +28,7 @@ typedef void* sde_stream_t; /* hipStream_t */
 #define SDE_MAX_CTX 4
 #define SDE_F32 0
 #define SDE_BF16 1
+#define SDE_F16 2 /* IEEE half storage, fp32 accumulate: BASELINE.json configs[4] (needs loss scaling: sde_adam_step's scale_state) */
 
 /* Partial-sum slabs (BatchNorm statistics, BN/bias backward reductions) must be allocated with SDE_REDUCE_ROWS extra rows:
  * slabs taller than that are first folded into their own tail by a deterministic two-level reduction. */

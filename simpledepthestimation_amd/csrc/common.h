@@ -56,3 +56,7 @@ __device__ __forceinline__ float sde_block_sum(float v, float* red) {
 typedef __bf16 bf16_t;
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+// fp16 storage (BASELINE.json configs[4]: fp16 + dynamic loss scaling): same kernels, instantiated on _Float16
+typedef _Float16 half_t;
+#define SDE_IS16(dtype) ((dtype) == SDE_BF16 || (dtype) == SDE_F16)
+#define SDE_DTYPE_OK(dtype) ((dtype) == SDE_F32 || (dtype) == SDE_BF16 || (dtype) == SDE_F16)

@@ -38,6 +38,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int V = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int V = 8; };
+template <> struct VecOf<half_t> { static constexpr int V = 8; };
 
 template <typename T>
 __device__ __forceinline__ uint4 gather16(const Gather& g, int n, int ih, int iw, int ci) {
@@ -64,6 +65,10 @@ template <typename T> __device__ __forceinline__ f32x4 mma64(const uint4& a, con
 template <> __device__ __forceinline__ f32x4 mma64<bf16_t>(const uint4& a, const uint4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+template <> __device__ __forceinline__ f32x4 mma64<half_t>(const uint4& a, const uint4& b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 template <> __device__ __forceinline__ f32x4 mma64<float>(const uint4& a, const uint4& b, f32x4 c) {
     // lane group g = lane>>4 holds k = 4g+j in element j: MFMA j contracts the 4 k's {4g+j}; A and B use the same map.
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
@@ -76,9 +81,11 @@ template <> __device__ __forceinline__ f32x4 mma64<float>(const uint4& a, const 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<half_t>(half_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ half_t from_f32<half_t>(float v) { return (half_t)v; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Forward / data-gradient implicit GEMM:  Y[M, Cout] = im2col(X)[M, K] * Wp[Cout, K]^T
@@ -706,6 +713,7 @@ struct WGradP {
 
 template <typename T> struct WGTraits;
 template <> struct WGTraits<bf16_t> { static constexpr int BR = 64; };   // pixels per stage
+template <> struct WGTraits<half_t> { static constexpr int BR = 64; };
 template <> struct WGTraits<float> { static constexpr int BR = 32; };
 
 // Transposed fragment read: rows of the LDS tile are pixels (reduction index), columns are output rows/cols.
@@ -736,6 +744,7 @@ template <> struct TrRead<bf16_t> {
 #endif
     }
 };
+template <> struct TrRead<half_t> : TrRead<bf16_t> {};      // the transposed LDS read moves 16-bit elements, whatever they encode
 template <> struct TrRead<float> {
     // 16 pixels per sub-block; element j of lane group g is pixel 4g+j (same map as mma64<float>)
     static __device__ __forceinline__ uint4 rd(const unsigned char* tile, int stride, int p0, int col0, int lane) {
@@ -1156,7 +1165,7 @@ int halo_bn(const Gather& g, int ldy) {
     return ldy > 32 ? 64 : (ldy > 16 ? 32 : 16);      // 64 wide at most: 3 waves / SIMD (measured 10.05 vs 10.10 ms/step against a 128-wide tile)
 }
 bool use_halo(const Gather& g, int dtype, int ldy) {
-    if (g_halo_min_blocks < 0 || dtype != SDE_BF16 || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.mode == SDE_SRC_ZEROINS) return false;
+    if (g_halo_min_blocks < 0 || !SDE_IS16(dtype) || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.mode == SDE_SRC_ZEROINS) return false;
     if (g.mode == SDE_SRC_UPCAT && !g.reflect) return false;
     if (g.Cin % 8 || g.OH < HT_H || g.OW < HT_W) return false;
     if (sde_cdiv(g.Cin, 64) * 64 * 3 > g.Cin * 4) return false;     // the tile stages 64-channel blocks: narrow inputs (Cin < 48) waste MFMA and LDS
@@ -1181,16 +1190,17 @@ int launch_halo(const IGemmP& p, hipStream_t s) {
     hipLaunchKernelGGL((halo3_kernel<T, BN, WM, WN, SRC>), grid, dim3(NTHREADS), lds, s, p);
     return 0;
 }
-template <int BN, int WM, int WN>
+template <typename T, int BN, int WM, int WN>
 int dispatch_halo_src(const IGemmP& p, hipStream_t s) {
-    if (p.g.mode == SDE_SRC_UPCAT) return launch_halo<bf16_t, BN, WM, WN, SRC_UPCAT_REFLECT>(p, s);
-    return p.g.reflect ? launch_halo<bf16_t, BN, WM, WN, SRC_PLAIN_REFLECT>(p, s) : launch_halo<bf16_t, BN, WM, WN, SRC_PLAIN_ZERO>(p, s);
+    if (p.g.mode == SDE_SRC_UPCAT) return launch_halo<T, BN, WM, WN, SRC_UPCAT_REFLECT>(p, s);
+    return p.g.reflect ? launch_halo<T, BN, WM, WN, SRC_PLAIN_REFLECT>(p, s) : launch_halo<T, BN, WM, WN, SRC_PLAIN_ZERO>(p, s);
 }
+template <typename T>
 int dispatch_halo(const IGemmP& p, hipStream_t s) {
     switch (halo_bn(p.g, p.ldy)) {
-        case 64: return dispatch_halo_src<64, 2, 2>(p, s);
-        case 32: return dispatch_halo_src<32, 4, 1>(p, s);
-        default: return dispatch_halo_src<16, 4, 1>(p, s);
+        case 64: return dispatch_halo_src<T, 64, 2, 2>(p, s);
+        case 32: return dispatch_halo_src<T, 32, 4, 1>(p, s);
+        default: return dispatch_halo_src<T, 16, 4, 1>(p, s);
     }
 }
 
@@ -1246,9 +1256,9 @@ int dispatch_wgrad(const WGradP& p, int splits, hipStream_t s) {
 }
 
 int fill_gather(const sde_conv_desc* d, Gather& g, const char* who) {
-    const int V = d->dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(d->dtype) ? 8 : 4;
     if (!(d->x0 && d->Bn > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0)) { sde_set_error("%s: bad descriptor", who); return SDE_ERR_ARG; }
-    if (d->dtype != SDE_F32 && d->dtype != SDE_BF16) { sde_set_error("%s: bad dtype %d", who, d->dtype); return SDE_ERR_ARG; }
+    if (!SDE_DTYPE_OK(d->dtype)) { sde_set_error("%s: bad dtype %d", who, d->dtype); return SDE_ERR_ARG; }
     if (d->C0 % V || d->C1 % V) { sde_set_error("%s: channel counts (%d,%d) must be multiples of %d", who, d->C0, d->C1, V); return SDE_ERR_ARG; }
     if (d->src_mode == SDE_SRC_UPCAT) {
         if (d->IH != 2 * d->H0 || d->IW != 2 * d->W0 || (d->C1 > 0 && !d->x1)) { sde_set_error("%s: upcat shape mismatch", who); return SDE_ERR_ARG; }
@@ -1274,7 +1284,7 @@ int fill_gather(const sde_conv_desc* d, Gather& g, const char* who) {
 namespace sdeconv {
 bool pgemm_applicable(const Gather& g, int dtype, int ldy);
 int pgemm_tile(long M, int ldy);
-int pgemm_run(const IGemmP& p, int depth, hipStream_t s);
+int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s);
 extern int g_pgemm_force_tile;
 }
 namespace {
@@ -1300,7 +1310,7 @@ static int pick_ksplit(const Gather& g, int dtype, int ldy) {
     if (!g_splitk || ldy % 4) return 1;
     if (pg ? pgemm_tile(g.M, ldy) != 64064 : (use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064)) return 1;
     const long tiles = (long)sde_cdiv(g.M, 64) * sde_cdiv(ldy, 64);
-    const int nk = sde_cdiv(g.Ktot, dtype == SDE_BF16 ? 64 : 32);
+    const int nk = sde_cdiv(g.Ktot, SDE_IS16(dtype) ? 64 : 32);
     // register-staged kernel (4 workgroups per CU, pipeline drained per tile): split below 384 tiles towards 768 workgroups (measured 10.12 ->
     // 9.73 ms/step, flat between 256 and 1024).  Persistent LDS-DMA kernel: only below one tile per CU (256), towards 512 -- the M = 5760
     // layers (360 tiles) measured 11-22 us unsplit against 18-28 us split three ways (profiles/r02_gemm_microbench.txt).
@@ -1330,14 +1340,17 @@ static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const flo
     }
     if (use_pgemm(p.g, d->dtype, ldy)) {
         SDE_CHECK_ARG((p.ksplit - 1) * sde_cdiv(p.g.Ktot / 64, p.ksplit) < p.g.Ktot / 64, "sde_conv_fwd: empty K split");
-        sdeconv::pgemm_run(p, g_pgemm_depth, (hipStream_t)stream);
-    } else if (use_halo(p.g, d->dtype, ldy)) dispatch_halo(p, (hipStream_t)stream);
-    else if (d->dtype == SDE_BF16) dispatch_igemm<bf16_t>(p, (hipStream_t)stream);
+        sdeconv::pgemm_run(p, d->dtype, g_pgemm_depth, (hipStream_t)stream);
+    } else if (use_halo(p.g, d->dtype, ldy)) {
+        if (d->dtype == SDE_BF16) dispatch_halo<bf16_t>(p, (hipStream_t)stream); else dispatch_halo<half_t>(p, (hipStream_t)stream);
+    } else if (d->dtype == SDE_BF16) dispatch_igemm<bf16_t>(p, (hipStream_t)stream);
+    else if (d->dtype == SDE_F16) dispatch_igemm<half_t>(p, (hipStream_t)stream);
     else dispatch_igemm<float>(p, (hipStream_t)stream);
     SDE_CHECK_LAUNCH("sde_conv_fwd");
     if (S > 1) {
         const unsigned nb = (unsigned)(sde_cdiv(p.g.M, 64) * sde_cdiv(ldy, 64));
         if (d->dtype == SDE_BF16) hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, ws, S, p.g.M, ldy, Cout, bias, act, (bf16_t*)y, stats);
+        else if (d->dtype == SDE_F16) hipLaunchKernelGGL(splitk_finish_kernel<half_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, ws, S, p.g.M, ldy, Cout, bias, act, (half_t*)y, stats);
         else hipLaunchKernelGGL(splitk_finish_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, ws, S, p.g.M, ldy, Cout, bias, act, (float*)y, stats);
         SDE_CHECK_LAUNCH("sde_conv_fwd/splitk_finish");
     }
@@ -1383,7 +1396,7 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     const long M = (long)d->Bn * d->OH * d->OW;
     const int Ktot = d->KH * d->KW * (d->C0 + d->C1);
     const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, 128);
-    const int BR = d->dtype == SDE_BF16 ? 64 : 32;
+    const int BR = SDE_IS16(d->dtype) ? 64 : 32;
     const long tgt = g_wgrad_blocks;            // default 256 = one workgroup per CU (sde_conv_set_option(SDE_OPT_WGRAD_BLOCKS, n))
     long want = (tgt + tiles - 1) / tiles;                  // default 256 (one workgroup per CU): measured best end to end -- every extra split is another fp32 slab through HBM
     const long max_by_rows = (M + 4 * BR - 1) / (4 * BR);   // at least 4 stages per split
@@ -1399,16 +1412,17 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     WGradP p;
     int rc = fill_gather(d, p.g, "sde_conv_wgrad");
     if (rc) return rc;
-    const int V = d->dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(d->dtype) ? 8 : 4;
     SDE_CHECK_ARG(Cout > 0 && ldd >= Cout && ldd % V == 0, "sde_conv_wgrad: bad Cout=%d ldd=%d", Cout, ldd);
     SDE_CHECK_ARG(splits >= 1, "sde_conv_wgrad: bad splits=%d", splits);
-    const int BR = d->dtype == SDE_BF16 ? 64 : 32;
+    const int BR = SDE_IS16(d->dtype) ? 64 : 32;
     int rps = sde_cdiv(p.g.M, splits);
     rps = sde_cdiv(rps, BR) * BR;
     SDE_CHECK_ARG((long)rps * splits >= p.g.M, "sde_conv_wgrad: split arithmetic");
     p.dy = dy; p.slab = slab; p.Cout = Cout; p.ldd = ldd; p.rows_per_split = rps;
-    p.single_buf = d->dtype == SDE_BF16 ? 1 : 0;      // one LDS stage buffer for the 16-bit tiles: 3 workgroups per CU, measured -0.7 % step time
+    p.single_buf = SDE_IS16(d->dtype) ? 1 : 0;      // one LDS stage buffer for the 16-bit tiles: 3 workgroups per CU, measured -0.7 % step time
     if (d->dtype == SDE_BF16) dispatch_wgrad<bf16_t>(p, splits, s);
+    else if (d->dtype == SDE_F16) dispatch_wgrad<half_t>(p, splits, s);
     else dispatch_wgrad<float>(p, splits, s);
     SDE_CHECK_LAUNCH("sde_conv_wgrad");
     g = p.g;
@@ -1475,15 +1489,17 @@ int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int
                     sde_stream_t stream) {
     SDE_CHECK_ARG(w && out, "sde_pack_weight: null pointer");
     SDE_CHECK_ARG(Cout > 0 && Cin > 0 && KH > 0 && KW > 0 && Cin_pad >= Cin && Cout_pad >= Cout, "sde_pack_weight: bad shape");
-    SDE_CHECK_ARG(dtype == SDE_F32 || dtype == SDE_BF16, "sde_pack_weight: bad dtype");
+    SDE_CHECK_ARG(SDE_DTYPE_OK(dtype), "sde_pack_weight: bad dtype");
     hipStream_t s = (hipStream_t)stream;
     const size_t total = for_dgrad ? (size_t)Cin_pad * KH * KW * Cout_pad : (size_t)Cout_pad * KH * KW * Cin_pad;
     const int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (for_dgrad) {
         if (dtype == SDE_BF16) hipLaunchKernelGGL(pack_w_dgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, w, (bf16_t*)out, Cout, Cin, KH, KW, Cout_pad, Cin_pad);
+        else if (dtype == SDE_F16) hipLaunchKernelGGL(pack_w_dgrad_kernel<half_t>, dim3(nb), dim3(256), 0, s, w, (half_t*)out, Cout, Cin, KH, KW, Cout_pad, Cin_pad);
         else hipLaunchKernelGGL(pack_w_dgrad_kernel<float>, dim3(nb), dim3(256), 0, s, w, (float*)out, Cout, Cin, KH, KW, Cout_pad, Cin_pad);
     } else {
         if (dtype == SDE_BF16) hipLaunchKernelGGL(pack_w_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, w, (bf16_t*)out, Cout, Cin, KH, KW, Cin_pad, Cout_pad);
+        else if (dtype == SDE_F16) hipLaunchKernelGGL(pack_w_fwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, w, (half_t*)out, Cout, Cin, KH, KW, Cin_pad, Cout_pad);
         else hipLaunchKernelGGL(pack_w_fwd_kernel<float>, dim3(nb), dim3(256), 0, s, w, (float*)out, Cout, Cin, KH, KW, Cin_pad, Cout_pad);
     }
     SDE_CHECK_LAUNCH("sde_pack_weight");
@@ -1520,8 +1536,9 @@ int sde_pack_item_blocks(int Cout_pad, int Cin_pad, int KH, int KW) {
 
 int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total_blocks, int dtype, sde_stream_t stream) {
     SDE_CHECK_ARG(items_dev && n > 0 && total_blocks > 0 && total_blocks < 0x7fffffffL, "sde_pack_weights_batched: bad argument");
-    SDE_CHECK_ARG(dtype == SDE_F32 || dtype == SDE_BF16, "sde_pack_weights_batched: bad dtype");
+    SDE_CHECK_ARG(SDE_DTYPE_OK(dtype), "sde_pack_weights_batched: bad dtype");
     if (dtype == SDE_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n);
+    else if (dtype == SDE_F16) hipLaunchKernelGGL(pack_batched_kernel<half_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n);
     else hipLaunchKernelGGL(pack_batched_kernel<float>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n);
     SDE_CHECK_LAUNCH("sde_pack_weights_batched");
     return SDE_OK;

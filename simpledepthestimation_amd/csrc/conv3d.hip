@@ -21,6 +21,7 @@ constexpr int WG_COLS = NF * (NT + 1);   // per-feature 27 weight gradients + 1 
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int V = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int V = 8; };
+template <> struct VecOf<half_t> { static constexpr int V = 8; };
 
 template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* o);
 template <> __device__ __forceinline__ void load_vec<float>(const float* p, float* o) {
@@ -33,6 +34,12 @@ template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, fl
 #pragma unroll
     for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(u[i] << 16); o[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
 }
+template <> __device__ __forceinline__ void load_vec<half_t>(const half_t* p, float* o) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    const h8 t = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)t[i];
+}
 template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* v);
 template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -42,6 +49,14 @@ template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const f
 #pragma unroll
     for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
     *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(t);
+}
+
+template <> __device__ __forceinline__ void store_vec<half_t>(half_t* p, const float* v) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    h8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = (_Float16)v[i];
+    *reinterpret_cast<h8*>(p) = t;
 }
 
 // the 16-byte group at p plus its two neighbours along the channel axis (zero outside [0, D))
@@ -233,14 +248,14 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_finalize_kernel(const float*
 
 int check_shape(const char* who, const void* a, const void* b, int B, int H, int W, int D, int dtype) {
     if (!a || !b) { sde_set_error("%s: null pointer", who); return SDE_ERR_ARG; }
-    if (dtype != SDE_F32 && dtype != SDE_BF16) { sde_set_error("%s: bad dtype %d", who, dtype); return SDE_ERR_ARG; }
-    const int V = dtype == SDE_BF16 ? 8 : 4;
+    if (!SDE_DTYPE_OK(dtype)) { sde_set_error("%s: bad dtype %d", who, dtype); return SDE_ERR_ARG; }
+    const int V = SDE_IS16(dtype) ? 8 : 4;
     if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || D % V) { sde_set_error("%s: bad shape B=%d H=%d W=%d D=%d (D %% %d)", who, B, H, W, D, V); return SDE_ERR_ARG; }
     if ((long)B * H * W * NF * D > 0x7fffffff0L) { sde_set_error("%s: tensor too large", who); return SDE_ERR_ARG; }
     return SDE_OK;
 }
 
-long n_items(int B, int H, int W, int D, int dtype) { return (long)B * H * W * (D / (dtype == SDE_BF16 ? 8 : 4)); }
+long n_items(int B, int H, int W, int D, int dtype) { return (long)B * H * W * (D / (SDE_IS16(dtype) ? 8 : 4)); }
 
 }  // namespace
 
@@ -252,6 +267,7 @@ int sde_conv3d_fwd(const void* x, const float* w, const float* bias, int B, int 
     SDE_CHECK_ARG(w, "sde_conv3d_fwd: null weights");
     const unsigned nb = (unsigned)((n_items(B, H, W, D, dtype) + 255) / 256);
     if (dtype == SDE_BF16) hipLaunchKernelGGL(conv3d_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, bias, (bf16_t*)y, B, H, W, D);
+    else if (dtype == SDE_F16) hipLaunchKernelGGL(conv3d_fwd_kernel<half_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, w, bias, (half_t*)y, B, H, W, D);
     else hipLaunchKernelGGL(conv3d_fwd_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, w, bias, (float*)y, B, H, W, D);
     SDE_CHECK_LAUNCH("sde_conv3d_fwd");
     return SDE_OK;
@@ -263,13 +279,14 @@ int sde_conv3d_dgrad(const void* dy, const float* w, int B, int H, int W, int D,
     SDE_CHECK_ARG(w, "sde_conv3d_dgrad: null weights");
     const unsigned nb = (unsigned)((n_items(B, H, W, D, dtype) + 255) / 256);
     if (dtype == SDE_BF16) hipLaunchKernelGGL(conv3d_dgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, w, (bf16_t*)dx, B, H, W, D);
+    else if (dtype == SDE_F16) hipLaunchKernelGGL(conv3d_dgrad_kernel<half_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const half_t*)dy, w, (half_t*)dx, B, H, W, D);
     else hipLaunchKernelGGL(conv3d_dgrad_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)dy, w, (float*)dx, B, H, W, D);
     SDE_CHECK_LAUNCH("sde_conv3d_dgrad");
     return SDE_OK;
 }
 
 int sde_conv3d_wgrad_num_blocks(int B, int H, int W, int D, int dtype) {
-    const int V = dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(dtype) ? 8 : 4;
     if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || D % V) return -1;
     return (int)((n_items(B, H, W, D, dtype) + 256 * WG_ITEMS - 1) / (256 * WG_ITEMS));
 }
@@ -281,6 +298,7 @@ int sde_conv3d_wgrad(const void* x, const void* dy, int B, int H, int W, int D, 
     SDE_CHECK_ARG(part && dw, "sde_conv3d_wgrad: null pointer");
     const int nb = sde_conv3d_wgrad_num_blocks(B, H, W, D, dtype);
     if (dtype == SDE_BF16) hipLaunchKernelGGL(conv3d_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, part, B, H, W, D);
+    else if (dtype == SDE_F16) hipLaunchKernelGGL(conv3d_wgrad_kernel<half_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy, part, B, H, W, D);
     else hipLaunchKernelGGL(conv3d_wgrad_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, part, B, H, W, D);
     SDE_CHECK_LAUNCH("sde_conv3d_wgrad");
     hipLaunchKernelGGL(conv3d_wgrad_finalize_kernel, dim3(WG_COLS), dim3(256), 0, (hipStream_t)stream, part, nb, dw, dbias, accumulate);

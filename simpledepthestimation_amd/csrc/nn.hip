@@ -20,6 +20,7 @@ namespace {
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { static constexpr int V = 4; };
 template <> struct VecOf<bf16_t> { static constexpr int V = 8; };
+template <> struct VecOf<half_t> { static constexpr int V = 8; };
 
 template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* v);
 template <> __device__ __forceinline__ void load_vec<float>(const float* p, float* v) {
@@ -35,6 +36,12 @@ template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, fl
         v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
     }
 }
+template <> __device__ __forceinline__ void load_vec<half_t>(const half_t* p, float* v) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    const h8 t = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
 template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* v);
 template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -44,6 +51,14 @@ template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const f
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
     *reinterpret_cast<uint4*>(p) = *reinterpret_cast<uint4*>(o);
+}
+
+template <> __device__ __forceinline__ void store_vec<half_t>(half_t* p, const float* v) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    h8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (_Float16)v[i];
+    *reinterpret_cast<h8*>(p) = o;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -917,10 +932,11 @@ int grid_for(long n_items) {
 
 }  // namespace
 
-#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
-    do {                                       \
-        if ((dtype) == SDE_BF16) { CALL_BF16; } \
-        else { CALL_F32; }                     \
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16, CALL_F16) \
+    do {                                        \
+        if ((dtype) == SDE_BF16) { CALL_BF16; }  \
+        else if ((dtype) == SDE_F16) { CALL_F16; } \
+        else { CALL_F32; }                      \
     } while (0)
 
 extern "C" {
@@ -932,7 +948,8 @@ int sde_prep_input(const float* img, const float* mean, const float* std_, int B
     hipStream_t s = (hipStream_t)stream;
     const int nb = grid_for((long)B * H * W);
     DISPATCH_T(dtype, hipLaunchKernelGGL(prep_input_kernel<float>, dim3(nb), dim3(256), 0, s, img, mean, std_, B, C, H, W, Cpad, flip, (float*)out),
-               hipLaunchKernelGGL(prep_input_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, img, mean, std_, B, C, H, W, Cpad, flip, (bf16_t*)out));
+               hipLaunchKernelGGL(prep_input_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, img, mean, std_, B, C, H, W, Cpad, flip, (bf16_t*)out),
+               hipLaunchKernelGGL(prep_input_kernel<half_t>, dim3(nb), dim3(256), 0, s, img, mean, std_, B, C, H, W, Cpad, flip, (half_t*)out));
     SDE_CHECK_LAUNCH("sde_prep_input");
     return SDE_OK;
 }
@@ -957,12 +974,13 @@ int sde_bn_eval_params(const float* gamma, const float* beta, const float* runni
 }
 
 int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu, long M, int C, int dtype, void* out, sde_stream_t stream) {
-    const int V = dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(y && bnp && out && M > 0 && C > 0 && C % V == 0, "sde_bn_apply: bad argument (C=%d)", C);
     hipStream_t s = (hipStream_t)stream;
     const int nb = grid_for(M * (C / V));
     DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)y, bnp, (const float*)residual, relu, M, C, (float*)out),
-               hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, bnp, (const bf16_t*)residual, relu, M, C, (bf16_t*)out));
+               hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, bnp, (const bf16_t*)residual, relu, M, C, (bf16_t*)out),
+               hipLaunchKernelGGL(bn_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)y, bnp, (const half_t*)residual, relu, M, C, (half_t*)out));
     SDE_CHECK_LAUNCH("sde_bn_apply");
     return SDE_OK;
 }
@@ -978,7 +996,7 @@ int sde_reduce_num_blocks(long M, int C) {
 
 int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, const float* gamma, int relu, long M, int C, int dtype, float* part,
                float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dy, void* dres, sde_stream_t stream) {
-    const int V = dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(dout && y && bnp && part && coef && dgamma && dbeta && dy && M > 0 && C > 0 && C % V == 0, "sde_bn_bwd: bad argument");
     SDE_CHECK_ARG(!relu || out, "sde_bn_bwd: relu needs the saved output");
     (void)gamma;
@@ -988,7 +1006,8 @@ int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bn
     const size_t lds = (2 * (size_t)C > 256 * 16 ? 2 * (size_t)C : 256 * 16) * sizeof(float);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)y, bnp, relu, M, C, rpb, part),
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part));
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part),
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<half_t>, dim3(nblk), dim3(256), lds, s, (const half_t*)dout, (const half_t*)out, (const half_t*)y, bnp, relu, M, C, rpb, part));
     SDE_CHECK_LAUNCH("sde_bn_bwd/reduce");
     int rows = nblk;
     const float* src = pre_reduce(part, rows, 2 * C, s);
@@ -997,38 +1016,41 @@ int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bn
     const int nb = grid_for(M * (C / V));
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)y, bnp, coef, relu, M, C, (float*)dy, (float*)dres),
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, coef, relu, M, C, (bf16_t*)dy, (bf16_t*)dres));
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, coef, relu, M, C, (bf16_t*)dy, (bf16_t*)dres),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dout, (const half_t*)out, (const half_t*)y, bnp, coef, relu, M, C, (half_t*)dy, (half_t*)dres));
     SDE_CHECK_LAUNCH("sde_bn_bwd/apply");
     return SDE_OK;
 }
 
 int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* out, uint8_t* idx, sde_stream_t stream) {
-    const int V = dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(x && out && idx && B > 0 && H > 1 && W > 1 && C % V == 0, "sde_maxpool_fwd: bad argument");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
     const int nb = grid_for((long)B * OH * OW * (C / V));
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, B, H, W, C, OH, OW, (float*)out, idx),
-               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, B, H, W, C, OH, OW, (bf16_t*)out, idx));
+               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, B, H, W, C, OH, OW, (bf16_t*)out, idx),
+               hipLaunchKernelGGL(maxpool_fwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)x, B, H, W, C, OH, OW, (half_t*)out, idx));
     SDE_CHECK_LAUNCH("sde_maxpool_fwd");
     return SDE_OK;
 }
 
 int sde_maxpool_bwd(const void* dout, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream) {
-    const int V = dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(dout && idx && dx && B > 0 && H > 1 && W > 1 && C % V == 0, "sde_maxpool_bwd: bad argument");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
     const int nb = grid_for((long)B * H * W * (C / V));
     DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, idx, B, H, W, C, OH, OW, (float*)dx),
-               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, idx, B, H, W, C, OH, OW, (bf16_t*)dx));
+               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, idx, B, H, W, C, OH, OW, (bf16_t*)dx),
+               hipLaunchKernelGGL(maxpool_bwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dout, idx, B, H, W, C, OH, OW, (half_t*)dx));
     SDE_CHECK_LAUNCH("sde_maxpool_bwd");
     return SDE_OK;
 }
 
 int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias, int accumulate,
                      sde_stream_t stream) {
-    const int V = dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(dout && M > 0 && C > 0 && C % V == 0, "sde_act_bwd_bias: bad argument");
     SDE_CHECK_ARG(act == SDE_ACT_NONE || out, "sde_act_bwd_bias: activation backward needs the saved output");
     SDE_CHECK_ARG((dbias == nullptr) || (part && Cbias > 0 && Cbias <= C), "sde_act_bwd_bias: bias gradient needs a partial slab");
@@ -1039,7 +1061,8 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
     const size_t lds = ((size_t)C > 256 * 8 ? (size_t)C : 256 * 8) * sizeof(float);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(act_bwd_bias_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, act, M, C, rpb, (float*)dz, p),
-               hipLaunchKernelGGL(act_bwd_bias_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, act, M, C, rpb, (bf16_t*)dz, p));
+               hipLaunchKernelGGL(act_bwd_bias_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, act, M, C, rpb, (bf16_t*)dz, p),
+               hipLaunchKernelGGL(act_bwd_bias_kernel<half_t>, dim3(nblk), dim3(256), lds, s, (const half_t*)dout, (const half_t*)out, act, M, C, rpb, (half_t*)dz, p));
     SDE_CHECK_LAUNCH("sde_act_bwd_bias");
     if (dbias) {
         int rows = nblk;
@@ -1051,14 +1074,15 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
 }
 
 int sde_refl_fold(const void* dxp, int B, int H, int W, int C, int C0, int upcat, int dtype, void* dx0, void* dx1, sde_stream_t stream) {
-    const int V = dtype == SDE_BF16 ? 8 : 4;
+    const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(dxp && dx0 && B > 0 && H >= 2 && W >= 2 && C % V == 0, "sde_refl_fold: bad argument (B=%d H=%d W=%d C=%d)", B, H, W, C);
     SDE_CHECK_ARG(!upcat || (C0 > 0 && C0 <= C && C0 % V == 0 && H % 2 == 0 && W % 2 == 0 && (C0 == C || dx1)), "sde_refl_fold: bad upcat argument");
     hipStream_t s = (hipStream_t)stream;
     const long items = upcat ? (long)B * (H / 2) * (W / 2) * (C0 / V) + (long)B * H * W * ((C - C0) / V) : (long)B * H * W * (C / V);
     const int nb = grid_for(items);
     DISPATCH_T(dtype, hipLaunchKernelGGL(refl_fold_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dxp, B, H, W, C, C0, upcat, (float*)dx0, (float*)dx1),
-               hipLaunchKernelGGL(refl_fold_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dxp, B, H, W, C, C0, upcat, (bf16_t*)dx0, (bf16_t*)dx1));
+               hipLaunchKernelGGL(refl_fold_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dxp, B, H, W, C, C0, upcat, (bf16_t*)dx0, (bf16_t*)dx1),
+               hipLaunchKernelGGL(refl_fold_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dxp, B, H, W, C, C0, upcat, (half_t*)dx0, (half_t*)dx1));
     SDE_CHECK_LAUNCH("sde_refl_fold");
     return SDE_OK;
 }
@@ -1069,7 +1093,8 @@ int sde_depth_head_fwd(const void* y, int B, int H, int W, int ld, float min_dep
     const float mind = 1.0f / max_depth, maxd = 1.0f / min_depth;
     const int nb = grid_for((long)B * H * W);
     DISPATCH_T(dtype, hipLaunchKernelGGL(depth_head_fwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)y, B, H, W, ld, mind, maxd, flip, depth),
-               hipLaunchKernelGGL(depth_head_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, B, H, W, ld, mind, maxd, flip, depth));
+               hipLaunchKernelGGL(depth_head_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, B, H, W, ld, mind, maxd, flip, depth),
+               hipLaunchKernelGGL(depth_head_fwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)y, B, H, W, ld, mind, maxd, flip, depth));
     SDE_CHECK_LAUNCH("sde_depth_head_fwd");
     return SDE_OK;
 }
@@ -1081,7 +1106,8 @@ int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, 
     const float mind = 1.0f / max_depth, maxd = 1.0f / min_depth;
     const int nb = grid_for((long)B * H * W);
     DISPATCH_T(dtype, hipLaunchKernelGGL(depth_head_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)y, ddepth, B, H, W, ld, mind, maxd, flip, (float*)dy),
-               hipLaunchKernelGGL(depth_head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, ddepth, B, H, W, ld, mind, maxd, flip, (bf16_t*)dy));
+               hipLaunchKernelGGL(depth_head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, ddepth, B, H, W, ld, mind, maxd, flip, (bf16_t*)dy),
+               hipLaunchKernelGGL(depth_head_bwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)y, ddepth, B, H, W, ld, mind, maxd, flip, (half_t*)dy));
     SDE_CHECK_LAUNCH("sde_depth_head_bwd");
     return SDE_OK;
 }
@@ -1089,17 +1115,19 @@ int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, 
 int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype, float* part, float* gnp,
                     void* out, sde_stream_t stream) {
     SDE_CHECK_ARG(x && gamma && beta && part && gnp && out && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "sde_gn_relu_fwd: bad argument");
-    SDE_CHECK_ARG(C % (dtype == SDE_BF16 ? 8 : 4) == 0, "sde_gn_relu_fwd: C=%d must be a multiple of the 16-byte group", C);
+    SDE_CHECK_ARG(C % (SDE_IS16(dtype) ? 8 : 4) == 0, "sde_gn_relu_fwd: C=%d must be a multiple of the 16-byte group", C);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)x, HW, C, part),
-               hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)x, HW, C, part));
+               hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)x, HW, C, part),
+               hipLaunchKernelGGL(gn_stats_kernel<half_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const half_t*)x, HW, C, part));
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/stats");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, s, part, B, C, G, HW, eps, gnp);
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/finalize");
-    const int nb = grid_for((long)B * HW * (C / (dtype == SDE_BF16 ? 8 : 4)));
+    const int nb = grid_for((long)B * HW * (C / (SDE_IS16(dtype) ? 8 : 4)));
     DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, gnp, gamma, beta, B, HW, C, G, relu, (float*)out),
-               hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, gnp, gamma, beta, B, HW, C, G, relu, (bf16_t*)out));
+               hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, gnp, gamma, beta, B, HW, C, G, relu, (bf16_t*)out),
+               hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)x, gnp, gamma, beta, B, HW, C, G, relu, (half_t*)out));
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/apply");
     return SDE_OK;
 }
@@ -1107,19 +1135,21 @@ int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B,
 int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,
                     float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream) {
     SDE_CHECK_ARG(dout && out && x && gnp && gamma && part && coef && dgamma && dbeta && dx && C % G == 0, "sde_gn_relu_bwd: bad argument");
-    SDE_CHECK_ARG(C % (dtype == SDE_BF16 ? 8 : 4) == 0, "sde_gn_relu_bwd: C=%d must be a multiple of the 16-byte group", C);
+    SDE_CHECK_ARG(C % (SDE_IS16(dtype) ? 8 : 4) == 0, "sde_gn_relu_bwd: C=%d must be a multiple of the 16-byte group", C);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)x, gnp, HW, C, G, relu, part),
-               hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, HW, C, G, relu, part));
+               hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, HW, C, G, relu, part),
+               hipLaunchKernelGGL(gn_bwd_stats_kernel<half_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const half_t*)dout, (const half_t*)out, (const half_t*)x, gnp, HW, C, G, relu, part));
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/stats");
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * G + C), dim3(64), 0, s, part, gamma, B, C, G, HW, coef, dgamma, dbeta, accumulate_params);
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/finalize");
-    const int nb = grid_for((long)B * HW * (C / (dtype == SDE_BF16 ? 8 : 4)));
+    const int nb = grid_for((long)B * HW * (C / (SDE_IS16(dtype) ? 8 : 4)));
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, gnp, coef, gamma, B, HW, C, G, relu, (float*)dx),
-               hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, coef, gamma, B, HW, C, G, relu, (bf16_t*)dx));
+               hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, coef, gamma, B, HW, C, G, relu, (bf16_t*)dx),
+               hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dout, (const half_t*)out, (const half_t*)x, gnp, coef, gamma, B, HW, C, G, relu, (half_t*)dx));
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/apply");
     return SDE_OK;
 }

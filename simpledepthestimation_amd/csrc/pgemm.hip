@@ -42,11 +42,26 @@ __device__ __forceinline__ void pg_dma4(__amdgpu_buffer_rsrc_t r, unsigned char*
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pg_lds_void*)lds, 4, voff, 0, 0, 0);
 }
 
-__device__ __forceinline__ unsigned pg_pack_bf16x2(float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
-    bf2 v = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, v);
-}
+// 16-bit storage type of the operands / outputs: bf16 or IEEE half (fp16 + loss scaling, BASELINE.json configs[4]); fp32 accumulate either way
+template <typename T16> struct PgType;
+template <> struct PgType<bf16_t> {
+    typedef pg_bf16x8 frag;
+    static __device__ __forceinline__ pg_f32x16 mma(frag a, frag b, pg_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+        v2 v = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+};
+template <> struct PgType<half_t> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 frag;
+    static __device__ __forceinline__ pg_f32x16 mma(frag a, frag b, pg_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+        v2 v = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(unsigned, v);
+    }
+};
 
 // LDS stores go through inline asm: hipcc orders every LDS store it can see behind ALL LDS-DMA still in flight (s_waitcnt vmcnt(0)), which
 // would drain the ring at every epilogue.  These stores only touch the slot that was just consumed; the caller waits lgkmcnt(0) itself.
@@ -83,8 +98,9 @@ __device__ __forceinline__ PGWork pg_work(const PGemmP& q, int w) {
     return r;
 }
 
-template <int BM, int BN, int SRC, int D>
+template <typename T16, int BM, int BN, int SRC, int D>
 __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
+    typedef typename PgType<T16>::frag frag_t;
     constexpr int WTM = BM / 2, WTN = BN / 2;          // 2 x 2 waves
     constexpr int FM = WTM / 32, FN = WTN / 32;        // 32x32 fragments per wave: pixels (MFMA columns) x channels (MFMA rows)
     constexpr int XP = BM / 32, WP = BN / 32;          // DMA pieces (8 rows x 128 B) per wave per stage
@@ -246,20 +262,20 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             __builtin_amdgcn_s_barrier();          // every wave's share has landed, and every wave is done with stage consumed-1
             issue_next();                          // refill the slot of stage consumed-1
             const unsigned char* slot = smem + (consumed % D) * SLOT_BYTES;
-            pg_bf16x8 wf[4][FN], xf[4][FM];
+            frag_t wf[4][FN], xf[4][FM];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) wf[kk][j] = *reinterpret_cast<const pg_bf16x8*>(slot + wrow0 + j * 32 * PG_STAGE_K_BYTES + koff[kk]);
+                for (int j = 0; j < FN; ++j) wf[kk][j] = *reinterpret_cast<const frag_t*>(slot + wrow0 + j * 32 * PG_STAGE_K_BYTES + koff[kk]);
 #pragma unroll
-                for (int i = 0; i < FM; ++i) xf[kk][i] = *reinterpret_cast<const pg_bf16x8*>(slot + xrow0 + i * 32 * PG_STAGE_K_BYTES + koff[kk]);
+                for (int i = 0; i < FM; ++i) xf[kk][i] = *reinterpret_cast<const frag_t*>(slot + xrow0 + i * 32 * PG_STAGE_K_BYTES + koff[kk]);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], xf[kk][i], acc[j][i], 0, 0, 0);
+                    for (int i = 0; i < FM; ++i) acc[j][i] = PgType<T16>::mma(wf[kk][j], xf[kk][i], acc[j][i]);
             ++consumed;
         }
 
@@ -306,7 +322,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
                             if (n0 + nt + e >= p.Cout) t = 0.f;       // padded output channels are exact zeros
                             v[e] = t;
                         }
-                        pg_lds_store8(sC_a + row * CST + (nt - ch * EN) * 2, pg_pack_bf16x2(v[0], v[1]), pg_pack_bf16x2(v[2], v[3]));
+                        pg_lds_store8(sC_a + row * CST + (nt - ch * EN) * 2, PgType<T16>::pack2(v[0], v[1]), PgType<T16>::pack2(v[2], v[3]));
                     }
                 }
             }
@@ -331,7 +347,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
                 const int rows = (g.M - m0) < BM ? (g.M - m0) : BM;
                 float s1 = 0.f, s2 = 0.f;
                 for (int r = part; r < rows; r += PARTS) {
-                    const float t = (float)*reinterpret_cast<const __bf16*>(sC + r * CST + c * 2);
+                    const float t = (float)*reinterpret_cast<const T16*>(sC + r * CST + c * 2);
                     s1 += t; s2 += t * t;
                 }
                 pg_lds_store8(sC_a + BM * CST + (part * EN + c) * 8, __builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2));
@@ -355,34 +371,34 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int SRC, int D>
+template <typename T16, int BM, int BN, int SRC, int D>
 static int pg_launch(const PGemmP& q, hipStream_t s) {
     constexpr int lds = D * ((BM + BN) * PG_STAGE_K_BYTES + BN * 4);      // stage ring + bias ring
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm_kernel<BM, BN, SRC, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm_kernel<T16, BM, BN, SRC, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     const int per_cu = (160 * 1024) / lds;
     int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     if (grid > q.total) grid = q.total;
-    hipLaunchKernelGGL((pgemm_kernel<BM, BN, SRC, D>), dim3(grid), dim3(PG_THREADS), lds, s, q);
+    hipLaunchKernelGGL((pgemm_kernel<T16, BM, BN, SRC, D>), dim3(grid), dim3(PG_THREADS), lds, s, q);
     return 0;
 }
 
-template <int BM, int BN, int D>
+template <typename T16, int BM, int BN, int D>
 static int pg_dispatch_src(const PGemmP& q, int src, hipStream_t s) {
     switch (src) {
-        case SRC_1X1: return pg_launch<BM, BN, SRC_1X1, D>(q, s);
-        case SRC_PLAIN_ZERO: return pg_launch<BM, BN, SRC_PLAIN_ZERO, D>(q, s);
-        case SRC_PLAIN_REFLECT: return pg_launch<BM, BN, SRC_PLAIN_REFLECT, D>(q, s);
-        default: return pg_launch<BM, BN, SRC_UPCAT_REFLECT, D>(q, s);
+        case SRC_1X1: return pg_launch<T16, BM, BN, SRC_1X1, D>(q, s);
+        case SRC_PLAIN_ZERO: return pg_launch<T16, BM, BN, SRC_PLAIN_ZERO, D>(q, s);
+        case SRC_PLAIN_REFLECT: return pg_launch<T16, BM, BN, SRC_PLAIN_REFLECT, D>(q, s);
+        default: return pg_launch<T16, BM, BN, SRC_UPCAT_REFLECT, D>(q, s);
     }
 }
 
 // The layers this kernel takes: bf16, every source a multiple of 64 channels (a stage is one filter tap x 64 channels), no zero insertion.
 bool pgemm_applicable(const Gather& g, int dtype, int ldy) {
-    if (dtype != SDE_BF16 || g.mode == SDE_SRC_ZEROINS) return false;
+    if (!SDE_IS16(dtype) || g.mode == SDE_SRC_ZEROINS) return false;
     if (g.Cin % 64 || g.C0 % 64 || (g.mode == SDE_SRC_UPCAT && !g.reflect)) return false;
     if (ldy % 8) return false;
     if ((long)g.Bn * g.IH * g.IW * (g.C0 > g.C1 ? g.C0 : g.C1) * 2L >= 0x7fffffffL) return false;      // 32-bit byte offsets
@@ -405,7 +421,14 @@ int pgemm_tile(long M, int ldy) {
     return g_pgemm_force_tile ? g_pgemm_force_tile : 64064;
 }
 
-int pgemm_run(const IGemmP& p, int depth, hipStream_t s) {
+template <typename T16>
+static int pgemm_run_t(const PGemmP& q, int tile, int src, int depth, hipStream_t s) {
+    if (tile == 128128) return pg_dispatch_src<T16, 128, 128, 3>(q, src, s);
+    if (tile == 128064) return depth == 3 ? pg_dispatch_src<T16, 128, 64, 3>(q, src, s) : pg_dispatch_src<T16, 128, 64, 4>(q, src, s);
+    return depth == 3 ? pg_dispatch_src<T16, 64, 64, 3>(q, src, s) : pg_dispatch_src<T16, 64, 64, 4>(q, src, s);
+}
+
+int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s) {
     PGemmP q;
     q.p = p;
     const int tile = pgemm_tile(p.g.M, p.ldy);
@@ -416,9 +439,7 @@ int pgemm_run(const IGemmP& p, int depth, hipStream_t s) {
     q.nk_total = p.g.Ktot / 64;
     q.nk_per = sde_cdiv(q.nk_total, p.ksplit);
     const int src = pgemm_src_kind(p.g);
-    if (tile == 128128) return pg_dispatch_src<128, 128, 3>(q, src, s);
-    if (tile == 128064) return depth == 3 ? pg_dispatch_src<128, 64, 3>(q, src, s) : pg_dispatch_src<128, 64, 4>(q, src, s);
-    return depth == 3 ? pg_dispatch_src<64, 64, 3>(q, src, s) : pg_dispatch_src<64, 64, 4>(q, src, s);
+    return dtype == SDE_F16 ? pgemm_run_t<half_t>(q, tile, src, depth, s) : pgemm_run_t<bf16_t>(q, tile, src, depth, s);
 }
 
 }  // namespace sdeconv

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("SDE_HIP_LIB", os.path.join(_HERE, "libsde_hip.so"))   # override: A/B builds of the same ABI
 MAX_CTX = 4
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 
 
 class SdeHipError(RuntimeError):

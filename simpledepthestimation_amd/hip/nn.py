@@ -1,6 +1,6 @@
 """Autograd wrappers over the convolution engine and its surrounding layers (include/sde_hip.h).
 
-Tensor convention: activations are NHWC torch tensors [B, H, W, C] (float32 or bfloat16), C padded to 16 bytes;
+Tensor convention: activations are NHWC torch tensors [B, H, W, C] (float32, bfloat16 or float16), C padded to 16 bytes;
 parameters stay fp32 in the reference's layouts (conv weight OIHW) so state dicts are interchangeable.
 """
 import ctypes
@@ -78,6 +78,8 @@ def dtype_code(dt):
         return L.F32
     if dt == torch.bfloat16:
         return L.BF16
+    if dt == torch.float16:
+        return L.F16
     raise L.SdeHipError(f"unsupported activation dtype {dt}")
 
 
@@ -141,7 +143,7 @@ def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device, kin
     variant = lib.sde_conv_fwd_variant(ctypes.byref(d), ldy) if L.PROFILE is not None else 0
     meta = None
     if L.PROFILE is not None:
-        esz = 2 if x_dtype == torch.bfloat16 else 4
+        esz = 4 if x_dtype == torch.float32 else 2
         meta = dict(M=d.Bn * d.OH * d.OW, N=ldy, K=d.KH * d.KW * (d.C0 + d.C1), k=d.KH, s=d.stride, mode=d.src_mode,
                     bytes=esz * (d.Bn * d.H0 * d.W0 * d.C0 + d.Bn * d.IH * d.IW * d.C1 + d.Bn * d.OH * d.OW * ldy))
     ws_bytes = lib.sde_conv_fwd_ws_bytes(ctypes.byref(d), ldy)           # > 0: small-M, long-K layer that runs split-K
@@ -242,7 +244,7 @@ class _Conv2d(torch.autograd.Function):
                 wslot = _grad_slot(ctx.params[0])
                 meta = None
                 if L.PROFILE is not None:
-                    esz = 2 if dt == torch.bfloat16 else 4
+                    esz = 4 if dt == torch.float32 else 2
                     meta = dict(M=M, N=Cout, K=KH * KW * (C0 + C1), k=KH, s=stride, mode=int(upcat), splits=splits,
                                 bytes=esz * (B * H0 * W0 * C0 + B * IH * IW * C1 + M * ldy) + 8 * splits * Cout * KH * KW * (C0 + C1))
                 forked = need_dx and L.SIDE_STREAM and L.PROFILE is None

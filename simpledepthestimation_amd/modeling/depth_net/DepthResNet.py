@@ -9,7 +9,8 @@ from ...layers.depth_decoder import DepthDecoder
 from ...layers.resnet_encoder import ResnetEncoder
 from .build import DEPTH_NET_REGISTRY
 
-_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+           "fp16": torch.float16, "float16": torch.float16}      # fp16: with SOLVER.AMP (dynamic loss scaling), BASELINE.json configs[4]
 
 
 def compute_dtype(cfg):

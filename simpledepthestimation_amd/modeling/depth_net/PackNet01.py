@@ -86,7 +86,7 @@ class PackNet01(nn.Module):
             parts.append(_up2(disp_below).unsqueeze(-1).to(self.dtype))
         if len(parts) == 1:
             return parts[0]
-        return _cat(parts, 8 if self.dtype == torch.bfloat16 else 4)
+        return _cat(parts, 4 if self.dtype == torch.float32 else 8)
 
     def forward(self, batch):
         flip = bool(batch.get("flip", False))

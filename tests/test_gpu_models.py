@@ -493,3 +493,74 @@ def test_graph_step_takes_the_collate_batch_dicts(tmp_path):
         finals.append({k: v.detach().clone() for k, v in model.module.state_dict().items()})
     for k in finals[0]:
         assert torch.equal(finals[0][k], finals[1][k]), k
+
+
+def _amp_cfg(arch, enc):
+    cfg = make_cfg(arch, enc, "fp16")
+    cfg.SOLVER.AMP = True
+    return cfg
+
+
+def test_fp16_forward_tracks_fp32():
+    """fp16 storage (BASELINE.json configs[4]'s precision): same weights, loss / depth close to the fp32 path (fp16 has 3 more mantissa bits
+    than bf16, so the bounds are those of the bf16 test or tighter)."""
+    sd = OM.init_state_dict(18, seed=3)
+    batch = sup_batch(2, 64, 192, 4)
+    m32 = build("SupDepthModel", 18, sd, "fp32").train()
+    m16 = build("SupDepthModel", 18, sd, "fp16").train()
+    o32 = m32(clone_batch(batch)); o16 = m16(clone_batch(batch))
+    assert abs(o16["silog_loss"].item() - o32["silog_loss"].item()) < 1e-2 * o32["silog_loss"].item()
+    assert rel(o16["depth_pred"][0], o32["depth_pred"][0]) < 1e-2
+
+
+@pytest.mark.parametrize("arch,enc", [("SupDepthModel", 18), ("MonoDepth2Model", "packnet1A")])
+def test_fp16_loss_scaling_steps_track_fp32_and_overflow_skips_the_step(arch, enc):
+    """SOLVER.AMP (the reference's AMPTrainer / GradScaler, detectron2/engine/train_loop.py:L294-341) on the device: fp16 steps with dynamic loss
+    scaling follow the fp32 trainer's losses; the scale backs off (x 0.5) while the scaled gradients overflow fp16 and such steps leave the
+    parameters and the Adam moments untouched; an injected inf is caught, skips exactly that step and halves the scale; growth after
+    `growth_interval` clean steps."""
+    from simpledepthestimation_amd.engine.trainer import monodepth2_trainer, supervised_trainer
+    sup = arch == "SupDepthModel"
+    mk = supervised_trainer if sup else monodepth2_trainer
+    sd = OM.init_state_dict(18, seed=3) if sup else OM.init_packnet_state_dict("A", seed=5)
+    raw = sup_batch(2, 64, 192, 4) if sup else mono_batch(1, 64, 192, 21)
+    batch = {k: ([x.to(dev) for x in v] if isinstance(v, list) else v.to(dev)) for k, v in raw.items()}
+    t32 = mk(build(arch, enc, sd, "fp32").train(), make_cfg(arch, enc, "fp32"))
+    t16 = mk(build(arch, enc, sd, "fp16").train(), _amp_cfg(arch, enc), growth_interval=3)
+    assert t16.amp and t16.scale_state is not None and float(t16.scale_state[0]) == 65536.0
+    with pytest.raises(ValueError):
+        mk(build(arch, enc, sd, "bf16").train(), (lambda c: (setattr(c.SOLVER, "AMP", True), c)[1])(make_cfg(arch, enc, "bf16")))
+    l32, l16, scales, moved = [], [], [], []
+    for _ in range(8):
+        p_before = t16.pflat.clone()
+        l32.append(sum(float(v) for v in t32.step(clone_batch(batch)).values()))
+        l16.append(sum(float(v) for v in t16.step(clone_batch(batch)).values()))
+        scales.append(float(t16.scale_state[0]))
+        moved.append(bool((t16.pflat != p_before).any()))
+    assert all(x == x and abs(x) != float("inf") for x in l16), l16
+    # every step either updated the parameters or backed the scale off; once the scale fits there are real updates
+    prev = 65536.0
+    for s, mv in zip(scales, moved):
+        assert (s == prev * 0.5 and not mv) or (s >= prev and mv), (scales, moved)
+        prev = s
+    assert sum(moved) >= 3, (scales, moved)
+    # the losses follow the fp32 run (skipped steps delay the fp16 trajectory: compare per number of applied updates)
+    k = sum(moved)
+    assert abs(l16[0] - l32[0]) < 2e-2 * abs(l32[0])
+    applied16 = [l for l, mv in zip(l16[1:], moved[:-1]) if mv]                   # loss seen after each applied update
+    for a, b in zip(applied16, l32[1:1 + len(applied16)]):
+        assert abs(a - b) < 6e-2 * abs(b), (l16, l32, moved)
+    # growth: three clean steps in a row double the scale
+    clean_runs = [i for i in range(2, len(scales)) if moved[i] and moved[i - 1] and moved[i - 2]]
+    if clean_runs:
+        assert any(scales[i] == 2.0 * scales[i - 1] for i in clean_runs) or scales[-1] > min(scales), scales
+    # injected overflow: one inf in the flat gradient -> the step is skipped (weights, moments) and the scale halves
+    t16._fwd_bwd(clone_batch(batch))
+    t16.gflat[7] = float("inf")
+    p0, m0, v0, s0 = t16.pflat.clone(), t16.m.clone(), t16.v.clone(), float(t16.scale_state[0])
+    t16._optimizer()
+    assert torch.equal(t16.pflat, p0) and torch.equal(t16.m, m0) and torch.equal(t16.v, v0)
+    assert float(t16.scale_state[0]) == 0.5 * s0 and float(t16.scale_state[1]) == 0.0
+    # the scale travels with the optimizer state
+    osd = t16.state_dict()
+    assert osd["loss_scale"] == 0.5 * s0
