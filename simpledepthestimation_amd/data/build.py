@@ -1,0 +1,149 @@
+"""Dataset registry and data loaders (reference: detectron2/data/build.py:L35-140, samplers/distributed_sampler.py:L57-84).
+
+``DatasetBase`` runs the configured preprocess chain forward (and backward on predictions); the train loader shards with
+torch's DistributedSampler (per-rank batch = IMS_PER_BATCH / world, drop_last), the test loader walks contiguous per-rank shards one image
+at a time.  ``DevicePrefetcher`` is the MI355X-side addition: batches are staged in pinned host memory and copied to HBM on a copy stream
+while the previous step's hipGraph replays, so the step never waits on PCIe (35-106 MB of fp32 images per step)."""
+import logging
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.utils.data as data
+
+from ..utils.registry import Registry
+from .preprocess import build_preprocess
+
+DATASET_REGISTRY = Registry("DATASET")
+
+
+def _world():
+    return (dist.get_world_size(), dist.get_rank()) if (dist.is_available() and dist.is_initialized()) else (1, 0)
+
+
+class DatasetBase(data.Dataset):
+    def __init__(self, dataset_cfg, cfg):
+        self.preprocesses = [build_preprocess(p) for p in dataset_cfg.get("PREPROCESS", [])]
+
+    def __getitem__(self, item):
+        raise NotImplementedError
+
+    def preprocess(self, data_dict):
+        for p in self.preprocesses:
+            data_dict = p.forward(data_dict)
+        return data_dict
+
+    def get_prediction(self, data_dict):
+        for p in self.preprocesses[::-1]:
+            data_dict = p.backward(data_dict)
+        return data_dict
+
+    def batch_collator(self, batch):
+        return data.default_collate(batch)
+
+
+class InferenceSampler(data.Sampler):
+    """Contiguous shards of exactly the dataset (ranks may differ by one sample), distributed_sampler.py:L57-84."""
+
+    def __init__(self, size):
+        assert size > 0
+        world, rank = _world()
+        shard = (size - 1) // world + 1
+        self._local_indices = range(shard * rank, min(shard * (rank + 1), size))
+
+    def __iter__(self):
+        yield from self._local_indices
+
+    def __len__(self):
+        return len(self._local_indices)
+
+
+def _seed_worker(worker_id):
+    import random
+    seed = np.random.randint(2 ** 31) + worker_id
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    random.seed(seed)
+
+
+def build_batch_data_loader(dataset, sampler, total_batch_size, *, num_workers=0):
+    world, _ = _world()
+    assert total_batch_size > 0 and total_batch_size % world == 0, \
+        f"Total batch size ({total_batch_size}) must be divisible by the number of gpus ({world})."
+    batch_sampler = data.BatchSampler(sampler, total_batch_size // world, drop_last=True)      # static shapes: what the captured hipGraph needs, too
+    return data.DataLoader(dataset, num_workers=num_workers, batch_sampler=batch_sampler, collate_fn=dataset.batch_collator, worker_init_fn=_seed_worker)
+
+
+def build_detection_train_loader(cfg):
+    dataset = DATASET_REGISTRY.get(cfg.DATASETS.TRAIN.NAME)(cfg.DATASETS.TRAIN, cfg)
+    assert isinstance(dataset, DatasetBase)
+    name = cfg.DATALOADER.get("SAMPLER_TRAIN", "DDPSampler")
+    logging.getLogger(__name__).info("Using training sampler %s", name)
+    if name != "DDPSampler":
+        raise ValueError(f"Unknown training sampler: {name}")      # the reference's TrainingSampler (infinite stream) has no user in the two projects
+    world, rank = _world()
+    sampler = data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True)
+    return build_batch_data_loader(dataset, sampler, cfg.SOLVER.IMS_PER_BATCH, num_workers=cfg.DATALOADER.NUM_WORKERS)
+
+
+def build_detection_test_loader(cfg):
+    if "TEST" not in cfg.DATASETS:
+        return None
+    dataset = DATASET_REGISTRY.get(cfg.DATASETS.TEST.NAME)(cfg.DATASETS.TEST, cfg)
+    assert isinstance(dataset, DatasetBase)
+    batch_sampler = data.BatchSampler(InferenceSampler(len(dataset)), 1, drop_last=False)      # one image per step at inference
+    return data.DataLoader(dataset, num_workers=cfg.DATALOADER.NUM_WORKERS, batch_sampler=batch_sampler, collate_fn=dataset.batch_collator)
+
+
+class DevicePrefetcher:
+    """Wraps a loader: batch k+1 is pinned and copied host -> device on a copy stream while step k runs; __next__ makes the consumer's
+    stream wait on the copy's event (no host synchronisation).  Arrays (tensors, numpy arrays, lists of them) move; everything else
+    (flip, metadata) passes through.  len() and re-iteration follow the wrapped loader."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _move(self, v):
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(np.ascontiguousarray(v))
+        if torch.is_tensor(v):
+            if self._stream is not None and v.device.type == "cpu":
+                v = v.pin_memory()
+            return v.to(self.device, non_blocking=True)
+        if isinstance(v, (list, tuple)) and v and all(isinstance(x, np.ndarray) or torch.is_tensor(x) for x in v):
+            return [self._move(x) for x in v]
+        return v
+
+    def _stage(self, batch):
+        if self._stream is None:
+            return {k: self._move(v) for k, v in batch.items()}, None
+        with torch.cuda.stream(self._stream):
+            out = {k: self._move(v) for k, v in batch.items()}
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        return out, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        nxt = None
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for v in cur.values():              # the tensors were allocated on the copy stream: tell the allocator who uses them now
+                    for t in (v if isinstance(v, list) else [v]):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(torch.cuda.current_stream(self.device))
+            yield cur
