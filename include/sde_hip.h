@@ -212,11 +212,14 @@ int sde_bn_eval_params(const float* gamma, const float* beta, const float* runni
                        sde_stream_t stream);
 /* out = [relu](y*scale + shift [+ residual]) */
 int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu, long M, int C, int dtype, void* out, sde_stream_t stream);
-/* BatchNorm(+ReLU, +residual) backward.  part: [sde_reduce_num_blocks(M, C) + SDE_REDUCE_ROWS][C][2] workspace, coef: [2][C] workspace.
- * dy [M,C]; dres (optional) [M,C] = gradient of the residual input; dgamma/dbeta [C] (+)=. */
+/* BatchNorm(+ReLU, +residual) backward.  The normalised output may have up to three consumers whose gradients arrive separately
+ * (dout, dout1, dout2; the latter two may be NULL): they are summed on the fly.  gm [M,C] (workspace, required when relu is set or more than
+ * one gradient is given) receives dz = relu'(out) * (sum of the gradients) -- which is also the gradient of the residual input.
+ * part: [sde_reduce_num_blocks(M, C) + SDE_REDUCE_ROWS][C][2] workspace, coef: [2][C] workspace.  dy [M,C]; dgamma/dbeta [C] (+)=. */
 int sde_reduce_num_blocks(long M, int C);
-int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, const float* gamma, int relu, long M, int C, int dtype, float* part,
-               float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dy, void* dres, sde_stream_t stream);
+int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const void* out, const void* y, const float* bnp, const float* gamma, int relu,
+               long M, int C, int dtype, float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* gm, void* dy,
+               sde_stream_t stream);
 
 /* nn.MaxPool2d(3, 2, 1) (resnet_encoder.py:L94).  idx: [B,OH,OW,C] u8 arg-max saved for backward. */
 int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* out, uint8_t* idx, sde_stream_t stream);

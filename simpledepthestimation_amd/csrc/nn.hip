@@ -190,10 +190,45 @@ __device__ __forceinline__ void block_group_reduce(float (&a)[NV], int cch, floa
 
 // Channel reduction pass of BN backward: partial[blk][C][2] = (sum dz, sum dz*xhat), dz = dout * (out > 0 if relu).
 // Grid-stride over (row, 16-byte group) items; gridDim*256 is a multiple of the groups per row, so a thread's group is fixed.
+// dz = relu'(out) * (dout0 [+ dout1] [+ dout2]): the block output feeds up to three consumers (next block's first convolution, its residual
+// path or down-sampling convolution, a decoder skip); their gradients arrive separately and are summed here instead of by an extra add
+// kernel per tensor.  When `gm` is given the masked sum is stored once (it IS the gradient of the residual input, and the apply pass reads it
+// instead of dout / out); per-block partial sums of dz and dz * xhat go to `part`.
+template <typename T, int V>
+__device__ __forceinline__ void round_vec(float* d) {       // values as they come back from storage type T
+    if (sizeof(T) == 4) return;
+#pragma unroll
+    for (int e = 0; e < V; ++e) d[e] = (float)(T)d[e];
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void bn_load_dz(const T* d0, const T* d1, const T* d2, const T* out, int relu, long off, float* d) {
+    load_vec<T>(d0 + off, d);
+    if (d1) {
+        float t[V];
+        load_vec<T>(d1 + off, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] += t[e];
+    }
+    if (d2) {
+        float t[V];
+        load_vec<T>(d2 + off, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] += t[e];
+    }
+    if (relu) {
+        float o[V];
+        load_vec<T>(out + off, o);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+    }
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y,
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ dout1, const T* __restrict__ dout2,
+                                                            const T* __restrict__ out, const T* __restrict__ y,
                                                             const float* __restrict__ bnp, int relu, long M, int C, long rows_per_block,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, T* __restrict__ gm) {
     constexpr int V = VecOf<T>::V;
     extern __shared__ float sh[];   // fast path: [256][2V]; fallback: [2][C]
     const int cch = C / V;
@@ -204,13 +239,12 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
         for (int e = 0; e < V; ++e) { mean[e] = bnp[c0 + e]; rstd[e] = bnp[C + c0 + e]; acc[e] = 0.f; acc[V + e] = 0.f; }
         const long total = M * cch;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-            float d[V], o[V], yv[V];
-            load_vec<T>(dout + i * V, d);
+            float d[V], yv[V];
+            bn_load_dz<T, V>(dout, dout1, dout2, out, relu, i * V, d);
             load_vec<T>(y + i * V, yv);
-            if (relu) {
-                load_vec<T>(out + i * V, o);
-#pragma unroll
-                for (int e = 0; e < V; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+            if (gm) {
+                round_vec<T, V>(d);              // the sums must see what the apply pass will read back
+                store_vec<T>(gm + i * V, d);
             }
 #pragma unroll
             for (int e = 0; e < V; ++e) { acc[e] += d[e]; acc[V + e] += d[e] * ((yv[e] - mean[e]) * rstd[e]); }
@@ -233,15 +267,17 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
     for (long i = threadIdx.x; i < total; i += 256) {
         const int col = (int)(i % cch), c0 = col * V;
         const long off = (r0 * cch + i) * V;
-        float d[V], o[V], yv[V];
-        load_vec<T>(dout + off, d);
-        if (relu) load_vec<T>(out + off, o);
+        float d[V], yv[V];
+        bn_load_dz<T, V>(dout, dout1, dout2, out, relu, off, d);
         load_vec<T>(y + off, yv);
+        if (gm) {
+            round_vec<T, V>(d);
+            store_vec<T>(gm + off, d);
+        }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const float dz = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
             const float xh = (yv[e] - bnp[c0 + e]) * bnp[C + c0 + e];
-            atomicAdd(&sh[c0 + e], dz); atomicAdd(&sh[C + c0 + e], dz * xh);
+            atomicAdd(&sh[c0 + e], d[e]); atomicAdd(&sh[C + c0 + e], d[e] * xh);
         }
     }
     __syncthreads();
@@ -265,29 +301,25 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
     dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
 }
 
-// dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat));  d_res = dz (optional)
+// dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat)), dz read back as the reduce pass left it (gm) or, for a single un-masked gradient, dout itself
 template <typename T>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ y,
-                                                           const float* __restrict__ bnp, const float* __restrict__ coef, int relu, long M, int C,
-                                                           T* __restrict__ dy, T* __restrict__ dres) {
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dz_in, const T* __restrict__ y,
+                                                           const float* __restrict__ bnp, const float* __restrict__ coef, long M, int C,
+                                                           T* __restrict__ dy) {
     constexpr int V = VecOf<T>::V;
     const int cch = C / V;
     const long total = M * cch;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % cch) * V;
-        float d[V], o[V], yv[V], g[V];
-        load_vec<T>(dout + i * V, d);
-        if (relu) load_vec<T>(out + i * V, o);
+        float d[V], yv[V], g[V];
+        load_vec<T>(dz_in + i * V, d);
         load_vec<T>(y + i * V, yv);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            const float dz = (relu && !(o[e] > 0.f)) ? 0.f : d[e];
             const float xh = (yv[e] - bnp[c0 + e]) * bnp[C + c0 + e];
-            g[e] = bnp[2 * C + c0 + e] * (dz - coef[c0 + e] - xh * coef[C + c0 + e]);
-            d[e] = dz;
+            g[e] = bnp[2 * C + c0 + e] * (d[e] - coef[c0 + e] - xh * coef[C + c0 + e]);
         }
         store_vec<T>(dy + i * V, g);
-        if (dres) store_vec<T>(dres + i * V, d);
     }
 }
 
@@ -994,30 +1026,34 @@ int sde_reduce_num_blocks(long M, int C) {
     return (int)nb;
 }
 
-int sde_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, const float* gamma, int relu, long M, int C, int dtype, float* part,
-               float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dy, void* dres, sde_stream_t stream) {
+int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const void* out, const void* y, const float* bnp, const float* gamma, int relu,
+               long M, int C, int dtype, float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* gm, void* dy,
+               sde_stream_t stream) {
     const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(dout && y && bnp && part && coef && dgamma && dbeta && dy && M > 0 && C > 0 && C % V == 0, "sde_bn_bwd: bad argument");
     SDE_CHECK_ARG(!relu || out, "sde_bn_bwd: relu needs the saved output");
+    SDE_CHECK_ARG(gm || (!relu && !dout1 && !dout2), "sde_bn_bwd: a masked or summed gradient needs the gm buffer");
+    SDE_CHECK_ARG(dout1 || !dout2, "sde_bn_bwd: dout2 without dout1");
     (void)gamma;
     hipStream_t s = (hipStream_t)stream;
     const int nblk = sde_reduce_num_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     const size_t lds = (2 * (size_t)C > 256 * 16 ? 2 * (size_t)C : 256 * 16) * sizeof(float);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)y, bnp, relu, M, C, rpb, part),
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part),
-               hipLaunchKernelGGL(bn_bwd_reduce_kernel<half_t>, dim3(nblk), dim3(256), lds, s, (const half_t*)dout, (const half_t*)out, (const half_t*)y, bnp, relu, M, C, rpb, part));
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)dout1, (const float*)dout2, (const float*)out, (const float*)y, bnp, relu, M, C, rpb, part, (float*)gm),
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)dout1, (const bf16_t*)dout2, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part, (bf16_t*)gm),
+               hipLaunchKernelGGL(bn_bwd_reduce_kernel<half_t>, dim3(nblk), dim3(256), lds, s, (const half_t*)dout, (const half_t*)dout1, (const half_t*)dout2, (const half_t*)out, (const half_t*)y, bnp, relu, M, C, rpb, part, (half_t*)gm));
     SDE_CHECK_LAUNCH("sde_bn_bwd/reduce");
     int rows = nblk;
     const float* src = pre_reduce(part, rows, 2 * C, s);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(256), 0, s, src, rows, C, (float)M, dgamma, dbeta, accumulate_params, coef);
     SDE_CHECK_LAUNCH("sde_bn_bwd/finalize");
     const int nb = grid_for(M * (C / V));
+    const void* dz = gm ? gm : dout;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)y, bnp, coef, relu, M, C, (float*)dy, (float*)dres),
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, coef, relu, M, C, (bf16_t*)dy, (bf16_t*)dres),
-               hipLaunchKernelGGL(bn_bwd_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dout, (const half_t*)out, (const half_t*)y, bnp, coef, relu, M, C, (half_t*)dy, (half_t*)dres));
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dz, (const float*)y, bnp, coef, M, C, (float*)dy),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, bnp, coef, M, C, (bf16_t*)dy),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dz, (const half_t*)y, bnp, coef, M, C, (half_t*)dy));
     SDE_CHECK_LAUNCH("sde_bn_bwd/apply");
     return SDE_OK;
 }

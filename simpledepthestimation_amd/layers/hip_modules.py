@@ -63,11 +63,11 @@ class HipBatchNorm2d(nn.Module):
         self._pending_batches = 0                  # the loaded num_batches_tracked is the whole count
         super()._load_from_state_dict(*args, **kwargs)
 
-    def forward(self, y, stats, residual=None, relu=True):
+    def forward(self, y, stats, residual=None, relu=True, n_out=1):
         if self.training:
             self._pending_batches += 1
         return HN.batch_norm_act(y, stats, self.weight, self.bias, self.running_mean, self.running_var, residual, relu, self.momentum, self.eps,
-                                 self.training)
+                                 self.training, n_out)
 
 
 class HipGroupNorm(nn.Module):
@@ -83,10 +83,11 @@ class HipGroupNorm(nn.Module):
         return HN.group_norm_relu(x, self.weight, self.bias, self.num_groups, self.eps, relu)
 
 
-def conv_bn(conv, bn, x, residual=None, relu=True):
-    """conv -> training-mode BatchNorm [-> + residual] [-> ReLU]; in eval mode BN uses its running statistics."""
+def conv_bn(conv, bn, x, residual=None, relu=True, n_out=1):
+    """conv -> training-mode BatchNorm [-> + residual] [-> ReLU]; in eval mode BN uses its running statistics.
+    n_out > 1: that many aliases of the result, one per consumer (see hip.nn._BatchNormAct)."""
     if bn.training:
         y, stats = conv(x, bn_stats=True)
     else:
         y, stats = conv(x), None
-    return bn(y, stats, residual, relu)
+    return bn(y, stats, residual, relu, n_out)

@@ -23,10 +23,11 @@ class BasicBlock(nn.Module):
         self.bn2 = HipBatchNorm2d(planes)
         self.downsample = downsample
 
-    def forward(self, x):
-        idt = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x, relu=False)
-        out = conv_bn(self.conv1, self.bn1, x)
-        return conv_bn(self.conv2, self.bn2, out, residual=idt, relu=True)
+    def forward(self, x, n_out=1):
+        xa, xb = x if isinstance(x, tuple) else (x, x)       # two aliases of the block input: one per consumer (see hip.nn._BatchNormAct)
+        idt = xb if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], xb, relu=False)
+        out = conv_bn(self.conv1, self.bn1, xa)
+        return conv_bn(self.conv2, self.bn2, out, residual=idt, relu=True, n_out=n_out)
 
 
 class Bottleneck(nn.Module):
@@ -42,11 +43,12 @@ class Bottleneck(nn.Module):
         self.bn3 = HipBatchNorm2d(planes * 4)
         self.downsample = downsample
 
-    def forward(self, x):
-        idt = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x, relu=False)
-        out = conv_bn(self.conv1, self.bn1, x)
+    def forward(self, x, n_out=1):
+        xa, xb = x if isinstance(x, tuple) else (x, x)       # two aliases of the block input: one per consumer (see hip.nn._BatchNormAct)
+        idt = xb if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], xb, relu=False)
+        out = conv_bn(self.conv1, self.bn1, xa)
         out = conv_bn(self.conv2, self.bn2, out)
-        return conv_bn(self.conv3, self.bn3, out, residual=idt, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=idt, relu=True, n_out=n_out)
 
 
 class ResNet(nn.Module):
@@ -101,12 +103,31 @@ class ResnetEncoder(nn.Module):
         cut (optional): callable(list_of_3_features) -> list of 3 detached leaves; layer3/layer4 then consume the leaves, so a
         backward pass from the loss stops there (HipTrainer's two-phase backward)."""
         e = self.encoder
+        split = torch.is_grad_enabled() and cut is None      # aliases only matter for backward; with a cut the features become leaves
+
+        def run(layer, x, last_n):
+            """The blocks of one layer; every block output but the last gets two aliases (conv1 + residual / down-sampling of the next block),
+            the last one `last_n` (next layer's two consumers + the decoder skip)."""
+            blocks = list(layer)
+            for i, blk in enumerate(blocks):
+                n = (2 if i + 1 < len(blocks) else last_n) if split else 1
+                x = blk(x, n_out=n)
+            return x
+
+        if split:
+            f0, f0_pool = conv_bn(e.conv1, e.bn1, x, n_out=2)            # decoder skip + max-pool
+            o1 = run(e.layer1, HN.max_pool_3x3_s2(f0_pool), 3)
+            o2 = run(e.layer2, (o1[1], o1[2]), 3)
+            o3 = run(e.layer3, (o2[1], o2[2]), 3)
+            f4 = run(e.layer4, (o3[1], o3[2]), 1)
+            self.features = [f0, o1[0], o2[0], o3[0], f4]
+            return self.features
         f0 = conv_bn(e.conv1, e.bn1, x)
-        f1 = e.layer1(HN.max_pool_3x3_s2(f0))
-        f2 = e.layer2(f1)
+        f1 = run(e.layer1, HN.max_pool_3x3_s2(f0), 1)
+        f2 = run(e.layer2, f1, 1)
         if cut is not None:
             f0, f1, f2 = cut([f0, f1, f2])
-        f3 = e.layer3(f2)
-        f4 = e.layer4(f3)
+        f3 = run(e.layer3, f2, 1)
+        f4 = run(e.layer4, f3, 1)
         self.features = [f0, f1, f2, f3, f4]
         return self.features

@@ -196,6 +196,50 @@ def test_conv_batchnorm(NN, dtype, C, with_res, relu):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("n_out,with_res,relu", [(3, True, True), (2, False, True), (2, False, False), (3, True, False)])
+def test_batchnorm_several_consumers(NN, dtype, n_out, with_res, relu):
+    """The block output feeds up to three consumers (next conv1, residual / down-sampling path, decoder skip): batch_norm_act(n_out) hands
+    each its own alias and backward sums the separately arriving gradients inside the BN-backward kernels (no autograd add kernels).
+    Some consumers may not contribute (None gradient)."""
+    g = torch.Generator().manual_seed(7 * n_out + int(relu))
+    V = 4 if dtype == torch.float32 else 8
+    B, H, W, Cin, C = 2, 10, 14, 16, 64
+    x = torch.randn(B, Cin, H, W, generator=g) + 0.2
+    w = torch.randn(C, Cin, 1, 1, generator=g) / math.sqrt(Cin)
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.2
+    res = torch.randn(B, C, H, W, generator=g) if with_res else None
+    cw = [torch.randn(B, C, H, W, generator=g) for _ in range(n_out)]          # consumer k: weighted sum of the output, scaled by (k + 1)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+        res = res.bfloat16().float() if with_res else None
+    xr, wr, gr, br = (t.clone().requires_grad_(True) for t in (x, w, gamma, beta))
+    rr = res.clone().requires_grad_(True) if with_res else None
+    yc = F.conv2d(xr, wr)
+    if dtype == torch.bfloat16:
+        yc = yc + (yc.detach().bfloat16().float() - yc.detach())
+    o = F.batch_norm(yc, torch.zeros(C), torch.ones(C), gr, br, True, 0.1, 1e-5)
+    o = o + rr if with_res else o
+    o = F.relu(o) if relu else o
+    used = list(range(n_out)) if n_out == 2 else [0, 2]                          # with three aliases the middle one stays unused
+    loss = sum(((k + 1) * (o * cw[k]).sum()) for k in used)
+    loss.backward()
+    xd = nhwc(x, dtype, V).requires_grad_(True)
+    wd, gd, bd = (t.clone().to(dev).requires_grad_(True) for t in (w, gamma, beta))
+    rd = nhwc(res, dtype, V).requires_grad_(True) if with_res else None
+    y, stats = NN.conv2d(xd, wd, None, bn_stats=True)
+    outs = NN.batch_norm_act(y, stats, gd, bd, torch.zeros(C, device=dev), torch.ones(C, device=dev), residual=rd, relu=relu, n_out=n_out)
+    assert len(outs) == n_out and all(t.data_ptr() == outs[0].data_ptr() for t in outs)
+    lossd = sum(((k + 1) * (outs[k].float() * nhwc(cw[k], torch.float32, 4)[..., :C].to(dev)).sum()) for k in used)
+    lossd.backward()
+    check(gd.grad.cpu(), gr.grad, dtype, "dgamma", 5e-5, 3e-2)
+    check(bd.grad.cpu(), br.grad, dtype, "dbeta", 5e-5, 3e-2)
+    check(nchw(xd.grad, Cin), xr.grad, dtype, "dX", 5e-5, 3e-2)
+    check(wd.grad.cpu(), wr.grad, dtype, "dW", 5e-5, 3e-2)
+    if with_res:
+        check(nchw(rd.grad, C), rr.grad, dtype, "dres", 5e-5, 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_maxpool(NN, dtype):
     g = torch.Generator().manual_seed(1)
     V = 4 if dtype == torch.float32 else 8
