@@ -139,12 +139,15 @@ int sde_pack_weight(const float* w, void* out, int dtype, int Cout, int Cin, int
  * built once; a workgroup transposes one (32 output channels x sde-chosen input-channel block x all taps) tile through LDS;
  * `end` = exclusive prefix sum of sde_pack_item_blocks() over the layers, total_blocks = items[n-1].end. */
 typedef struct sde_pack_item {
-    const float* src; /* master OIHW fp32 [Cout][Cin][KH][KW] */
+    const float* src; /* master fp32 weights: [Cout][Cin][KH][KW] (src_layout SDE_W_OIHW) or [Cout][KH][KW][Cin] (SDE_W_OHWI, channels-last) */
     void* dst_fwd;    /* [Cout_pad][KH][KW][Cin_pad] in `dtype` (or NULL) */
     void* dst_dgrad;  /* [Cin_pad][KH][KW][Cout_pad], taps flipped (or NULL) */
     int32_t Cout, Cin, KH, KW, Cin_pad, Cout_pad;
+    int32_t src_layout, reserved;
     int64_t end;
 } sde_pack_item;
+#define SDE_W_OIHW 0 /* torch's default memory order of a conv weight */
+#define SDE_W_OHWI 1 /* torch.channels_last order of the same [Cout,Cin,KH,KW] tensor: K-major like the packed operands and the gradient slabs */
 int sde_pack_item_blocks(int Cout_pad, int Cin_pad, int KH, int KW);
 int sde_pack_weights_batched(const sde_pack_item* items_dev, int n, long total_blocks, int dtype, sde_stream_t stream);
 
@@ -191,9 +194,12 @@ int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, in
 int sde_conv_wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int ldd, float* slab, int splits, sde_stream_t stream);
 typedef struct sde_wreduce_item {
     const float* slab; /* the slab stack sde_conv_wgrad_partial filled (device) */
-    float* dw;         /* master OIHW fp32 gradient [Cout,Cin_real,KH,KW] (device) */
-    int32_t rows /* = splits */, Cout, KHW, Cin_pad, Cin_real, accumulate;
+    float* dw;         /* master fp32 gradient of the [Cout,Cin_real,KH,KW] weight (device), in OIHW or OHWI memory order */
+    int32_t rows /* = splits */, Cout, KHW, Cin_pad, Cin_real;
+    int32_t accumulate; /* bit 0: add to dw instead of overwriting; bit 1 (SDE_WREDUCE_OHWI): dw is in OHWI (channels-last) order */
 } sde_wreduce_item;
+#define SDE_WREDUCE_ACCUMULATE 1
+#define SDE_WREDUCE_OHWI 2
 int sde_wgrad_reduce_batched(const sde_wreduce_item* items, int n, sde_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------

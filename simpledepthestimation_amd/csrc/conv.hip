@@ -962,7 +962,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduce
     }
     const WReduceArg it = batch.it[lo];
     const int co = b - (lo ? batch.it[lo - 1].end : 0);
-    const int KHW = it.KHW, Cin_pad = it.Cin_pad, K = KHW * Cin_pad, Cout = it.Cout, splits = it.splits, chunk = it.chunk;
+    const int KHW = it.KHW, Cin_pad = it.Cin_pad, K = KHW * Cin_pad, Cout = it.Cout, splits = it.splits, chunk = it.chunk & 0x7fff;
+    const bool ohwi = (it.chunk & 0x8000) != 0;          // dw in channels-last order [co][tap][ci]: no transpose on the way out
     const int cin_real = it.Cin_real & 0x7fff, accumulate = it.Cin_real >> 15;
     const int CB = wreduce_cb(KHW, Cin_pad, batch.lds_floats);
     const size_t total4 = (size_t)Cout * K / 4;                     // K is a multiple of 4: rows are walked as float4 (16 B per lane)
@@ -1002,6 +1003,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduce
         }
         __syncthreads();
         const int creal = min(cb, cin_real - ci0);                  // real channels of this chunk (<= 0: padding only)
+        if (ohwi) {
+            for (int j = threadIdx.x; j < creal * KHW; j += 256) {
+                const int tap = j / creal, ci = j - tap * creal;
+                const float v = sk[tap * cb + ci];
+                float* dst = o + (size_t)tap * cin_real + ci0 + ci;
+                *dst = accumulate ? *dst + v : v;
+            }
+        } else
         for (int j = threadIdx.x; j < creal * KHW; j += 256) {
             const int ci = j / KHW, tap = j - ci * KHW;
             const float v = sk[tap * cb + ci];
@@ -1010,6 +1019,54 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduce
         }
         __syncthreads();
     }
+}
+
+// Channels-last gradients (SDE_WREDUCE_OHWI) of layers without channel padding have exactly the slab's memory order: the reduction is then
+// a plain fixed-order sum of float4 rows -- no LDS, no transpose, every access a whole 16-byte group of consecutive lanes.
+// One workgroup = 1024 consecutive floats of one item; same summation order as the kernel above (chunk sums of even / odd rows, four ways).
+__global__ void __launch_bounds__(256) wgrad_sum_batched_kernel(const WReduceBatch batch) {
+    int lo = 0, hi = batch.n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (batch.it[mid].end > b) hi = mid; else lo = mid + 1;
+    }
+    const WReduceArg it = batch.it[lo];
+    const int local = b - (lo ? batch.it[lo - 1].end : 0);
+    const size_t total4 = (size_t)it.Cout * it.KHW * it.Cin_pad / 4;
+    const size_t q = (size_t)local * 256 + threadIdx.x;
+    if (q >= total4) return;
+    const int splits = it.splits, chunk = it.chunk & 0x7fff, accumulate = it.Cin_real >> 15;
+    const float4* src = reinterpret_cast<const float4*>(it.slab) + q;
+    auto add4 = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+    const float4 z = {0.f, 0.f, 0.f, 0.f};
+    float4 s0 = z, s1 = z, s2 = z, s3 = z;
+    if (chunk == 1) {
+        int sp = 0;
+        for (; sp + 3 < splits; sp += 4) {
+            add4(s0, src[(size_t)sp * total4]); add4(s1, src[(size_t)(sp + 1) * total4]);
+            add4(s2, src[(size_t)(sp + 2) * total4]); add4(s3, src[(size_t)(sp + 3) * total4]);
+        }
+        for (; sp < splits; ++sp) add4(s0, src[(size_t)sp * total4]);
+    } else {
+        auto part = [&](int ro) {
+            const int r0 = ro * chunk, r1 = min(splits, r0 + chunk);
+            float4 a = z, c = z;
+            int r = r0;
+            for (; r + 1 < r1; r += 2) { add4(a, src[(size_t)r * total4]); add4(c, src[(size_t)(r + 1) * total4]); }
+            if (r < r1) add4(a, src[(size_t)r * total4]);
+            add4(a, c);
+            return a;
+        };
+        const int rows = (splits + chunk - 1) / chunk;
+        int ro = 0;
+        for (; ro + 3 < rows; ro += 4) { add4(s0, part(ro)); add4(s1, part(ro + 1)); add4(s2, part(ro + 2)); add4(s3, part(ro + 3)); }
+        for (; ro < rows; ++ro) add4(s0, part(ro));
+    }
+    add4(s0, s1); add4(s2, s3); add4(s0, s2);
+    float4* dst = reinterpret_cast<float4*>(it.dw) + q;
+    if (accumulate) { const float4 o = *dst; add4(s0, o); }
+    *dst = s0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1074,7 +1131,13 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const sde_pack_item* 
     const int n_ci_real = max(0, min(CI, it.Cin - ci0));          // channels that exist in the master weights
     const int n_ci = min(CI, it.Cin_pad - ci0), n_co = min(PACK_CO, it.Cout_pad - co0);
     const int seg = n_ci_real * khw, rs = CI * khw + 1;           // row stride odd: the transposed reads below are conflict-free
-    if (seg > 0)
+    if (seg > 0 && it.src_layout == SDE_W_OHWI) {      // channels-last master weights [co][tap][ci]: contiguous along ci
+        for (int idx = threadIdx.x; idx < PACK_CO * seg; idx += 256) {
+            const int ci_l = idx % n_ci_real, t2 = idx / n_ci_real, tap = t2 % khw, co_l = t2 / khw;
+            const int co = co0 + co_l;
+            tile[co_l * rs + ci_l * khw + tap] = co < it.Cout ? it.src[((size_t)co * khw + tap) * it.Cin + ci0 + ci_l] : 0.f;
+        }
+    } else if (seg > 0)
         for (int idx = threadIdx.x; idx < PACK_CO * seg; idx += 256) {
             const int co_l = idx / seg, e = idx - co_l * seg;
             const int co = co0 + co_l;
@@ -1429,35 +1492,58 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     return SDE_OK;
 }
 
-static int launch_wreduce(const sde_wreduce_item* items, int n, hipStream_t s) {
-    for (int i = 0; i < n; ++i) {
-        const sde_wreduce_item& it = items[i];
+static int launch_wreduce(const sde_wreduce_item* items_in, int n_in, hipStream_t s) {
+    for (int i = 0; i < n_in; ++i) {
+        const sde_wreduce_item& it = items_in[i];
         SDE_CHECK_ARG(it.slab && it.dw && it.rows >= 1 && it.rows <= 65535 && it.Cout >= 1 && it.Cout <= 65535 && it.KHW >= 1 && it.KHW <= 4096 &&
                           it.Cin_pad >= 4 && it.Cin_pad <= 32767 && it.Cin_pad % 4 == 0 && it.Cin_real >= 1 && it.Cin_real <= it.Cin_pad,
                       "sde_wgrad_reduce_batched: item %d out of range", i);
         SDE_CHECK_ARG(((uintptr_t)it.slab & 15) == 0, "sde_wgrad_reduce_batched: item %d: unaligned slab", i);
     }
-    for (int i0 = 0; i0 < n; i0 += WREDUCE_MAX) {
-        WReduceBatch batch;
-        batch.n = n - i0 < WREDUCE_MAX ? n - i0 : WREDUCE_MAX; batch.lds_floats = WREDUCE_LDS_FLOATS;
-        int end = 0, need = 0;
-        for (int i = 0; i < batch.n; ++i) {
-            const sde_wreduce_item& it = items[i0 + i];
-            end += it.Cout;
-            const int lds = it.KHW * wreduce_cb(it.KHW, it.Cin_pad, WREDUCE_LDS_FLOATS);
-            if (lds > need) need = lds;
-            const int chunk = it.rows > SDE_WGRAD_FOLD_ROWS ? sde_cdiv(it.rows, SDE_WGRAD_FOLD_ROWS) : 1;
-            batch.it[i] = WReduceArg{it.slab, it.dw, end, (unsigned short)it.rows, (unsigned short)chunk, (unsigned short)it.Cout, (unsigned short)it.KHW,
-                                     (unsigned short)it.Cin_pad, (unsigned short)(it.Cin_real | (it.accumulate ? 0x8000 : 0))};
+    // streaming form: channels-last gradient, no channel padding, 16-byte aligned slot -> the slab rows ARE gradient rows
+    auto streams = [](const sde_wreduce_item& it) {
+        return (it.accumulate & SDE_WREDUCE_OHWI) && it.Cin_pad == it.Cin_real && ((uintptr_t)it.dw & 15) == 0;
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+        sde_wreduce_item sel[WREDUCE_MAX];
+        int n = 0;
+        auto flush = [&]() -> int {
+            if (n == 0) return SDE_OK;
+            WReduceBatch batch;
+            batch.n = n; batch.lds_floats = WREDUCE_LDS_FLOATS;
+            int end = 0, need = 0;
+            for (int i = 0; i < n; ++i) {
+                const sde_wreduce_item& it = sel[i];
+                end += pass == 0 ? sde_cdiv((long)it.Cout * it.KHW * it.Cin_pad / 4, 256) : it.Cout;
+                const int lds = it.KHW * wreduce_cb(it.KHW, it.Cin_pad, WREDUCE_LDS_FLOATS);
+                if (lds > need) need = lds;
+                const int chunk = it.rows > SDE_WGRAD_FOLD_ROWS ? sde_cdiv(it.rows, SDE_WGRAD_FOLD_ROWS) : 1;
+                batch.it[i] = WReduceArg{it.slab, it.dw, end, (unsigned short)it.rows, (unsigned short)(chunk | ((it.accumulate & SDE_WREDUCE_OHWI) ? 0x8000 : 0)),
+                                         (unsigned short)it.Cout, (unsigned short)it.KHW, (unsigned short)it.Cin_pad,
+                                         (unsigned short)(it.Cin_real | ((it.accumulate & SDE_WREDUCE_ACCUMULATE) ? 0x8000 : 0))};
+            }
+            for (int i = n; i < WREDUCE_MAX; ++i) batch.it[i] = WReduceArg{nullptr, nullptr, end, 0, 0, 0, 0, 0, 0};
+            if (pass == 0) {
+                hipLaunchKernelGGL(wgrad_sum_batched_kernel, dim3((unsigned)end), dim3(256), 0, s, batch);
+            } else {
+                static bool attr_done = false;
+                if (!attr_done) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr_done = true;
+                }
+                hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)end), dim3(256), (size_t)need * sizeof(float), s, batch);
+            }
+            SDE_CHECK_LAUNCH("sde_wgrad_reduce_batched");
+            n = 0;
+            return SDE_OK;
+        };
+        for (int i = 0; i < n_in; ++i) {
+            if (streams(items_in[i]) != (pass == 0)) continue;
+            sel[n++] = items_in[i];
+            if (n == WREDUCE_MAX) { const int rc = flush(); if (rc) return rc; }
         }
-        for (int i = batch.n; i < WREDUCE_MAX; ++i) batch.it[i] = WReduceArg{nullptr, nullptr, end, 0, 0, 0, 0, 0, 0};
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_reduce_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)end), dim3(256), (size_t)need * sizeof(float), s, batch);
-        SDE_CHECK_LAUNCH("sde_wgrad_reduce_batched");
+        const int rc = flush();
+        if (rc) return rc;
     }
     return SDE_OK;
 }
@@ -1470,7 +1556,7 @@ int sde_conv_wgrad(const sde_conv_desc* d, const void* dy, int Cout, int ldd, in
     int rc = wgrad_partial(d, dy, Cout, ldd, slab, splits, s, g);
     if (rc) return rc;
     SDE_CHECK_ARG(Cin_real >= 1 && Cin_real <= g.Cin, "sde_conv_wgrad: bad Cin_real=%d", Cin_real);
-    const sde_wreduce_item it = {slab, dw, splits, Cout, d->KH * d->KW, g.Cin, Cin_real, accumulate};
+    const sde_wreduce_item it = {slab, dw, splits, Cout, d->KH * d->KW, g.Cin, Cin_real, accumulate};      // accumulate: SDE_WREDUCE_* bits
     return launch_wreduce(&it, 1, s);
 }
 

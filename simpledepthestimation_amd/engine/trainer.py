@@ -34,6 +34,22 @@ class ParamGroup:
         self.name, self.named_params, self.lr, self.weight_decay = name, list(named_params), float(lr), float(weight_decay)
 
 
+def flat_view(buf, off, p):
+    """The slice of a flat buffer that belongs to parameter p, shaped like p.  4-D (convolution) weights live in the buffers channels-last --
+    memory order [Cout][KH][KW][Cin], the order of the packed MFMA operands and of the weight-gradient slabs, so the per-step weight pack is a
+    cast and the slab reduction a plain sum -- under the usual [Cout,Cin,KH,KW] shape; state dicts, torch.optim state and gradient comparisons
+    see logical tensors and never notice."""
+    n = p.numel()
+    if p.dim() == 4:
+        Cout, Cin, KH, KW = p.shape
+        return buf[off:off + n].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+    return buf[off:off + n].view(p.shape)
+
+
+def _slot(n):
+    return (n + 3) & ~3
+
+
 class GradCut:
     """Splits the autograd graph at a set of activations (the encoder features feeding layer3 and the decoder skips).
 
@@ -73,20 +89,21 @@ class HipTrainer:
             kept = [(n, p) for n, p in g.named_params if p.requires_grad and not any(s in n for s in skip_unused)]
             self.groups.append(ParamGroup(g.name, kept, g.lr, g.weight_decay))
             self._all_names.append([n for n, _ in g.named_params])
-            total += sum(p.numel() for _, p in kept)
-        self.numel = total
-        self.pflat = torch.empty(total, device=dev, dtype=torch.float32)
+            total += sum(_slot(p.numel()) for _, p in kept)
+        self.numel = total             # every parameter starts on a 16-byte boundary of the flat buffers (float4 kernels); the padding stays zero
+        self.pflat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self._off = {}                 # id(parameter) -> offset of its slot
         self.gflat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.m = torch.zeros(total, device=dev, dtype=torch.float32)
         self.v = torch.zeros(total, device=dev, dtype=torch.float32)
         off, seg_end = 0, []
         for g in self.groups:
             for _, p in g.named_params:
-                n = p.numel()
-                self.pflat[off:off + n].copy_(p.data.reshape(-1))
-                p.data = self.pflat[off:off + n].view(p.shape)
-                p.grad = self.gflat[off:off + n].view(p.shape)
-                off += n
+                self._off[id(p)] = off
+                flat_view(self.pflat, off, p).copy_(p.data)
+                p.data = flat_view(self.pflat, off, p)
+                p.grad = flat_view(self.gflat, off, p)
+                off += _slot(p.numel())
             seg_end.append(off)
         self.seg_end = seg_end         # host tables: the optimizer kernel takes them by value (no upload to order against the launch)
         self.t = 0
@@ -108,8 +125,7 @@ class HipTrainer:
             for g in self.groups:
                 for n, p in g.named_params:
                     if self.late_start == total and any(t in n for t in late_from):
-                        self.late_start = off
-                    off += p.numel()
+                        self.late_start = self._off[id(p)]
             if self.late_start < total:
                 self._cut = GradCut()
                 owner._grad_cut = self._cut
@@ -138,17 +154,16 @@ class HipTrainer:
     # registration order; every parameter carries {'step', 'exp_avg', 'exp_avg_sq'}.  'param_names' is an addition that lets a load
     # match by name when the numbering differs (the reference's encoder group also holds the unused fc.weight / fc.bias).
     def state_dict(self):
-        state, groups, idx, off = {}, [], 0, 0
+        state, groups, idx = {}, [], 0
         for g in self.groups:
             ids = []
             for _, p in g.named_params:
-                n = p.numel()
+                off = self._off[id(p)]
                 if self.t > 0:
-                    state[idx] = {"step": torch.tensor(float(self.t)), "exp_avg": self.m[off:off + n].view(p.shape).detach().cpu().clone(),
-                                  "exp_avg_sq": self.v[off:off + n].view(p.shape).detach().cpu().clone()}
+                    state[idx] = {"step": torch.tensor(float(self.t)), "exp_avg": flat_view(self.m, off, p).detach().cpu().contiguous().clone(),
+                                  "exp_avg_sq": flat_view(self.v, off, p).detach().cpu().contiguous().clone()}
                 ids.append(idx)
                 idx += 1
-                off += n
             groups.append({"lr": g.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": g.weight_decay, "amsgrad": False,
                            "params": ids, "param_names": [n for n, _ in g.named_params], "name": g.name})
         out = {"state": state, "param_groups": groups}
@@ -167,7 +182,7 @@ class HipTrainer:
         if len(their_groups) != len(self.groups):
             raise ValueError(f"optimizer checkpoint has {len(their_groups)} parameter groups, this trainer {len(self.groups)}")
         state = {int(k): v for k, v in sd["state"].items()}
-        plan, steps, off = [], [], 0
+        plan, steps = [], []
         for g, tg, all_names in zip(self.groups, their_groups, self._all_names):
             names = tg.get("param_names")
             ids = list(tg["params"])
@@ -181,23 +196,22 @@ class HipTrainer:
                 raise ValueError(f"optimizer group '{g.name}': checkpoint lists {len(ids)} parameters, the model registers {len(all_names)} "
                                  f"({len(g.named_params)} of them trained)")
             for n, p in g.named_params:
-                k = p.numel()
+                off = self._off[id(p)]
                 ent = state.get(by_name.get(n))
                 if ent is not None:
                     for key in ("exp_avg", "exp_avg_sq"):
                         if tuple(ent[key].shape) != tuple(p.shape):
                             raise ValueError(f"optimizer state {by_name.get(n)} ({key}) has shape {tuple(ent[key].shape)}, parameter '{n}' {tuple(p.shape)}")
-                    plan.append((off, k, ent))
+                    plan.append((off, p, ent))
                     steps.append(int(float(ent["step"])))
-                off += k
         if steps and min(steps) != max(steps):
             raise ValueError("per-parameter step counts differ; the fused Adam kernel keeps one step count for all parameters")
         # ---- validated: now write
         self.m.zero_()
         self.v.zero_()
-        for off, k, ent in plan:
-            self.m[off:off + k].copy_(ent["exp_avg"].reshape(-1).to(self.m))
-            self.v[off:off + k].copy_(ent["exp_avg_sq"].reshape(-1).to(self.v))
+        for off, p, ent in plan:
+            flat_view(self.m, off, p).copy_(ent["exp_avg"].to(self.m))
+            flat_view(self.v, off, p).copy_(ent["exp_avg_sq"].to(self.v))
         for g, tg in zip(self.groups, their_groups):
             g.lr, g.weight_decay = float(tg.get("lr", g.lr)), float(tg.get("weight_decay", g.weight_decay))
         self.t = steps[0] if steps else 0

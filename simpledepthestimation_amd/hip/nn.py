@@ -91,11 +91,21 @@ def pad_to(c, v):
     return (c + v - 1) // v * v
 
 
+def is_ohwi(t):
+    """A 4-D conv weight (or its gradient) stored channels-last: memory order [Cout][KH][KW][Cin] under the usual [Cout,Cin,KH,KW] shape -- the
+    order of the packed operands and of the weight-gradient slabs (HipTrainer lays its flat buffers out this way)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _dense(t):
+    return t.is_contiguous() or is_ohwi(t)
+
+
 def _grad_slot(p):
     """A parameter's pre-allocated fp32 .grad (HipTrainer points it into the flat gradient buffer): kernels then accumulate
     straight into it and the Function returns None for that input, which skips autograd's per-parameter add kernel."""
     g = p.grad if (p is not None and p.is_leaf) else None
-    if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape:
+    if g is not None and g.dtype == torch.float32 and _dense(g) and g.shape == p.shape:
         return g
     return None
 
@@ -267,22 +277,35 @@ class _Conv2d(torch.autograd.Function):
                 else:
                     import contextlib
                     wctx = contextlib.nullcontext()
-                dw = wslot if wslot is not None else torch.empty_like(weight)
+                dw = wslot if wslot is not None else torch.empty(weight.shape, device=dev)      # a fresh gradient tensor is plain OIHW
+                wflags = (1 if wslot is not None else 0) | (2 if is_ohwi(dw) else 0)                # SDE_WREDUCE_ACCUMULATE | SDE_WREDUCE_OHWI
                 # small slab stacks wait for the phase's one batched reduction; big ones (ResNet-50's 20-40 MB stacks add up to ~1 GB per step)
                 # are summed at once on the side stream while they are still in the Infinity Cache and their block can be recycled
                 slab_bytes = 4 * splits * Cout * KH * KW * (C0 + C1)
                 defer = WGRAD_DEFER if (wslot is not None and WGRAD_DEFER is not None and slab_bytes <= L.DEFER_MAX_BYTES and WGRAD_DEFER.accepts(wslot)) else None
-                slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
+                # one pixel range and a channels-last slot without channel padding: the GEMM's only "slab" IS the gradient row block -- it writes
+                # straight into the (zeroed) flat gradient, nothing to reduce.  (A second use of the same weight in the phase accumulates normally.)
+                direct = (splits == 1 and wslot is not None and WGRAD_DEFER is not None and WGRAD_DEFER.accepts(wslot) and (C0 + C1) == Cin
+                          and (KH * KW == 1 or is_ohwi(wslot)) and wslot.data_ptr() % 16 == 0 and L.PROFILE is None)
+                if direct:
+                    WGRAD_DEFER._seen.add(wslot.data_ptr())
+                    slab, slab_p, defer = wslot, _wptr(wslot), None
+                else:
+                    slab = torch.empty(splits, Cout, KH * KW * (C0 + C1), device=dev)
+                    slab_p = L.ptr(slab)
                 if grouped:
                     side_g = L.side_stream(rotate=False)
-                    if defer is not None:
-                        defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin)
+                    if direct:
+                        def launch(d=d):
+                            L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, slab_p, 1, L.stream()), "sde_conv_wgrad_partial")
+                    elif defer is not None:
+                        defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin, wflags)
                         def launch(d=d, slab=slab):
                             L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits, L.stream()), "sde_conv_wgrad_partial")
                             slab.record_stream(side_g)
                     else:
                         def launch(d=d, slab=slab, dw=dw):
-                            L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw), int(wslot is not None), L.stream()),
+                            L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, _wptr(dw), wflags, L.stream()),
                                     "sde_conv_wgrad")
                             slab.record_stream(side_g)
                     WGRAD_DEFER.queue.append((launch, (dz, x0, x1, slab, dw)))
@@ -291,21 +314,23 @@ class _Conv2d(torch.autograd.Function):
                     st["dw"], st["forked"], st["side"] = (None if wslot is not None else dw), False, None
                     return
                 with wctx:
-                    if defer is not None:
+                    if direct:
+                        L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, slab_p, 1, L.stream()), "sde_conv_wgrad_partial")
+                    elif defer is not None:
                         _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits, L.stream()),
                                                                   "sde_conv_wgrad_partial"), meta)
-                        defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin)
+                        defer.add(slab, slab.data_ptr(), splits, wslot, Cout, KH * KW, C0 + C1, Cin, wflags)
                     else:
                         if L.PROFILE is None:
-                            L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, L.ptr(dw), int(wslot is not None), L.stream()),
+                            L.check(lib.sde_conv_wgrad(ctypes.byref(d), L.ptr(dz), Cout, ldy, Cin, L.ptr(slab), splits, _wptr(dw), wflags, L.stream()),
                                     "sde_conv_wgrad")
                         else:       # the same two launches, timed separately (bench.py's roofline pass: GEMM FLOPs against GEMM time)
                             _timed("wgrad", flops, 0, lambda: L.check(lib.sde_conv_wgrad_partial(ctypes.byref(d), L.ptr(dz), Cout, ldy, L.ptr(slab), splits,
                                                                                                  L.stream()), "sde_conv_wgrad_partial"), meta)
-                            one = (WReduceItem * 1)(WReduceItem(slab.data_ptr(), dw.data_ptr(), splits, Cout, KH * KW, C0 + C1, Cin, int(wslot is not None)))
+                            one = (WReduceItem * 1)(WReduceItem(slab.data_ptr(), dw.data_ptr(), splits, Cout, KH * KW, C0 + C1, Cin, wflags))
                             _timed("wgrad_reduce", 0.0, 0, lambda: L.check(lib.sde_wgrad_reduce_batched(one, 1, L.stream()), "sde_wgrad_reduce_batched"),
                                    dict(jobs=1))
-                    if forked:
+                    if forked and not direct:
                         slab.record_stream(side)
                 if wslot is not None:
                     dw = None
@@ -349,6 +374,13 @@ class _Conv2d(torch.autograd.Function):
             else:
                 torch.cuda.current_stream().wait_stream(side)       # join: dz / x0 / x1 stay alive until both GEMMs are done
         return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
+
+
+def _wptr(t):
+    """Device pointer of a dense conv-weight-shaped tensor in either memory order (L.ptr insists on torch-contiguous tensors)."""
+    if not (t.is_cuda and _dense(t)):
+        raise L.SdeHipError("weight gradient buffer must be a dense CUDA tensor (OIHW or channels-last)")
+    return c_void_p(t.data_ptr())
 
 
 class WReduceItem(Structure):
@@ -398,9 +430,9 @@ class WGradReducer:
         # a weight used twice in one phase (shared modules) must not be accumulated by two blocks of one launch: the second use reduces at once
         return wslot.data_ptr() not in self._seen
 
-    def add(self, slab, src_ptr, rows, wslot, Cout, KHW, Cin_pad, Cin_real):
+    def add(self, slab, src_ptr, rows, wslot, Cout, KHW, Cin_pad, Cin_real, flags=1):
         self._seen.add(wslot.data_ptr())
-        self.jobs.append((slab, wslot, (src_ptr, wslot.data_ptr(), rows, Cout, KHW, Cin_pad, Cin_real, 1)))
+        self.jobs.append((slab, wslot, (src_ptr, wslot.data_ptr(), rows, Cout, KHW, Cin_pad, Cin_real, flags)))
 
     def flush(self):
         self.run_queue()
@@ -434,7 +466,7 @@ FOLD_ROWS = 16          # SDE_WGRAD_FOLD_ROWS
 
 class PackItem(Structure):
     _fields_ = [("src", c_void_p), ("dst_fwd", c_void_p), ("dst_dgrad", c_void_p), ("Cout", c_int32), ("Cin", c_int32), ("KH", c_int32), ("KW", c_int32),
-                ("Cin_pad", c_int32), ("Cout_pad", c_int32), ("end", ctypes.c_int64)]
+                ("Cin_pad", c_int32), ("Cout_pad", c_int32), ("src_layout", c_int32), ("reserved", c_int32), ("end", ctypes.c_int64)]
 
 
 class WeightPacker:
@@ -464,7 +496,9 @@ class WeightPacker:
             if nb <= 0:
                 raise L.SdeHipError(f"WeightPacker: unsupported kernel size {KH}x{KW}")
             end += nb
-            items.append((w.data_ptr(), wp.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, cin_pad, ldy, end))
+            if not _dense(w):
+                raise L.SdeHipError("WeightPacker: conv weights must be dense (OIHW or channels-last)")
+            items.append((w.data_ptr(), wp.data_ptr(), wd.data_ptr(), Cout, Cin, KH, KW, cin_pad, ldy, 1 if is_ohwi(w) else 0, 0, end))
             self._keep.append((w, wp, wd))
         dev = convs[0].weight.device
 

@@ -166,7 +166,7 @@ def test_dp2_two_phase_backward_matches_single_process():
 def test_flat_views_alias_parameters():
     model = _make(0)
     tr = _trainer(model)
-    n = sum(p.numel() for p in model.parameters())
+    n = sum((p.numel() + 3) // 4 * 4 for p in model.parameters())          # every parameter slot starts on a 16-byte boundary
     assert tr.numel == n and tr.pflat.numel() == n
     for p in model.parameters():
         assert p.data.data_ptr() >= tr.pflat.data_ptr() and p.data.data_ptr() < tr.pflat.data_ptr() + 4 * n

@@ -63,6 +63,6 @@ def test_set_lr_is_host_side_and_reaches_the_optimizer():
     tr.step(batch)
     tr.set_lr([3e-3, 4e-3])
     tr.step(batch)
-    assert seen[0] == ([35, 41], [1e-2, 5e-3], [1e-2, 0.0]) and seen[1][1] == [3e-3, 4e-3]
+    assert seen[0] == ([40, 52], [1e-2, 5e-3], [1e-2, 0.0]) and seen[1][1] == [3e-3, 4e-3]      # 30 + 5 -> 32 + 8; 5 + 1 -> 8 + 4 (16-byte slots)
     with pytest.raises(ValueError):
         tr.set_lr([1.0])
