@@ -1371,7 +1371,7 @@ extern "C" {
 static int pick_ksplit(const Gather& g, int dtype, int ldy) {
     const bool pg = use_pgemm(g, dtype, ldy);
     if (!g_splitk || ldy % 4) return 1;
-    if (pg ? pgemm_tile(g.M, ldy) != 64064 : (use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064)) return 1;
+    if (pg ? (pgemm_tile(g.M, ldy) != 64064 || g.mode == SDE_SRC_ZEROINS) : (use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064)) return 1;
     const long tiles = (long)sde_cdiv(g.M, 64) * sde_cdiv(ldy, 64);
     const int nk = sde_cdiv(g.Ktot, SDE_IS16(dtype) ? 64 : 32);
     // register-staged kernel (4 workgroups per CU, pipeline drained per tile): split below 384 tiles towards 768 workgroups (measured 10.12 ->

@@ -76,17 +76,48 @@ struct PGemmP {
     IGemmP p;
     int tiles_n, tiles_mn, total;       // work items = tiles_mn * ksplit, N tiles of one M tile adjacent
     int nk_total, nk_per;               // K stages of the whole GEMM / per split
+    // SRC_ZEROINS_ZERO (data gradient of a stride-2 convolution) only: the output pixels are split into the four parity classes of
+    // (row, column); class c = 2a + b owns the filter taps th = a, a+2, ... / tw = b, b+2, ... -- the only ones that meet a real (not an
+    // inserted zero) gradient pixel -- so every class is a dense GEMM with K = (its taps) x C instead of all KH*KW taps at 1/4 density.
+    int cls_end[4];                     // exclusive prefix sums of the classes' tile counts (tiles_m(c) * tiles_n)
+    int zero_siblings;                  // 1x1 kernels: only class 0 has a tap; its tiles also write the zeros of the other three pixels of each 2x2 cell
 };
 
 // One work item: tile (tile_m, tile_n), K stages [s_begin, s_begin + nk)
 struct PGWork {
     int tile_m, tile_n, split, s_begin, nk;
+    int cls;                            // parity class (SRC_ZEROINS_ZERO)
 };
 
-template <int BM, int BN>
+// geometry of a parity class of the zero-insertion gather (g: virtual input = zero-inserted dz, stride 1, pad p = KH-1-pad_fwd)
+struct PGClass {
+    int a, b, ih0, iw0, IHc, IWc, nta, ntb, M;
+};
+__host__ __device__ inline PGClass pg_class(const Gather& g, int c) {
+    PGClass k;
+    k.a = c >> 1; k.b = c & 1;
+    k.ih0 = (k.a + g.pad) & 1; k.iw0 = (k.b + g.pad) & 1;           // output rows ih with (ih - pad + th) even for th = a (mod 2)
+    k.IHc = g.OH > k.ih0 ? (g.OH - k.ih0 + 1) / 2 : 0; k.IWc = g.OW > k.iw0 ? (g.OW - k.iw0 + 1) / 2 : 0;
+    k.nta = g.KH > k.a ? (g.KH - k.a + 1) / 2 : 0; k.ntb = g.KW > k.b ? (g.KW - k.b + 1) / 2 : 0;
+    k.M = g.Bn * k.IHc * k.IWc;
+    return k;
+}
+
+template <int BM, int BN, int SRC>
 __device__ __forceinline__ PGWork pg_work(const PGemmP& q, int w) {
     PGWork r;
     const int logical = xcd_remap(w, q.total);
+    if (SRC == SRC_ZEROINS_ZERO) {
+        int c = 0;
+        while (c < 3 && logical >= q.cls_end[c]) ++c;
+        const int local = logical - (c ? q.cls_end[c - 1] : 0);
+        const PGClass k = pg_class(q.p.g, c);
+        r.cls = c; r.split = 0; r.s_begin = 0;
+        r.tile_m = local / q.tiles_n; r.tile_n = local - r.tile_m * q.tiles_n;
+        r.nk = k.nta * k.ntb * (q.p.g.C0 / 64);
+        return r;
+    }
+    r.cls = 0;
     r.split = logical / q.tiles_mn;
     const int rem = logical - r.split * q.tiles_mn;
     r.tile_m = rem / q.tiles_n;
@@ -134,7 +165,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     const int drow = lane >> 3, dslot = lane & 7;
     // ---- load cursor (runs D-1 stages ahead of the compute cursor, across work items)
     int lw = blockIdx.x;                 // work item being loaded
-    PGWork lwk = pg_work<BM, BN>(q, lw < q.total ? lw : 0);
+    PGWork lwk = pg_work<BM, BN, SRC>(q, lw < q.total ? lw : 0);
     if (lw >= q.total) lwk.nk = 0;
     int ls = 0;                          // next stage of that item
     int l_item = 0;                      // items started by the load cursor (bias ring slot = l_item % D)
@@ -142,9 +173,37 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     unsigned xbase[XP];                  // per row: byte offset of the pixel (tap (0,0), channel 0) + this lane's swizzled chunk, or kOOB
     int xih[XP], xiw[XP], xnb[XP];       // per row: input coordinate of tap (0,0) and image index (gather kinds with taps)
     unsigned woff[WP];                   // per weight row: byte offset of row + swizzled chunk, or kOOB
+    int l_a = 0, l_b = 0, l_nta = 1, l_ntb = 1;      // SRC_ZEROINS_ZERO: parity class of the item being loaded, its tap counts
 
     auto setup_item = [&]() {            // per-lane addressing state of work item `lwk`
         const int m0 = lwk.tile_m * BM, n0 = lwk.tile_n * BN;
+        if (SRC == SRC_ZEROINS_ZERO) {
+            const PGClass k = pg_class(g, lwk.cls);
+            l_a = k.a; l_b = k.b; l_nta = k.nta; l_ntb = k.ntb;
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int row = wave * (BM / 4) + i * 8 + drow;
+                const int chunk = dslot ^ ((row >> 1) & 7);
+                const int m = m0 + row;
+                const bool ok = m < k.M;
+                const int mm = ok ? m : 0;
+                const int n = mm / (k.IHc * k.IWc);
+                const int rem = mm - n * (k.IHc * k.IWc);
+                const int ci = rem / k.IWc, cj = rem - ci * k.IWc;
+                // source pixel of tap (a + 2 ta, b + 2 tb): (ci + (ih0 - pad + a) / 2 + ta, cj + (iw0 - pad + b) / 2 + tb)  [the halves are exact]
+                xih[i] = ci + ((k.ih0 - g.pad + k.a) >> 1); xiw[i] = cj + ((k.iw0 - g.pad + k.b) >> 1); xnb[i] = ok ? n : -1;
+                xbase[i] = ok ? (unsigned)(((n * g.H0 + xih[i]) * g.W0 + xiw[i]) * g.C0 * 2 + chunk * 16) : kOOB;
+            }
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                const int row = wave * (BN / 4) + i * 8 + drow;
+                const int chunk = dslot ^ ((row >> 1) & 7);
+                const int n = n0 + row;
+                woff[i] = n < p.ldy ? (unsigned)(n * g.Ktot * 2 + chunk * 16) : kOOB;
+            }
+            l_cb = 0; l_kh = 0; l_kw = 0;         // here: tap COUNTERS ta, tb inside the class
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int row = wave * (BM / 4) + i * 8 + drow;
@@ -183,10 +242,19 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
         unsigned char* slot = smem + (issued % D) * SLOT_BYTES;
         unsigned char* sX = slot + (wave * (BM / 4)) * PG_STAGE_K_BYTES;
         unsigned char* sW = slot + BM * PG_STAGE_K_BYTES + (wave * (BN / 4)) * PG_STAGE_K_BYTES;
-        const unsigned soff = (unsigned)(lwk.s_begin + ls) * (unsigned)PG_STAGE_K_BYTES;
+        const unsigned soff = SRC == SRC_ZEROINS_ZERO
+                                  ? (unsigned)((((l_a + 2 * l_kh) * g.KW + l_b + 2 * l_kw) * g.C0 + l_cb) * 2)      // K position of tap (a + 2 ta, b + 2 tb), channel block cb
+                                  : (unsigned)(lwk.s_begin + ls) * (unsigned)PG_STAGE_K_BYTES;
 #pragma unroll
         for (int i = 0; i < WP; ++i) pg_dma16(rsw, sW + i * 1024, woff[i], soff);
-        if (SRC == SRC_1X1) {
+        if (SRC == SRC_ZEROINS_ZERO) {
+            const unsigned toff = (unsigned)(((l_kh * g.W0 + l_kw) * g.C0 + l_cb) * 2);
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const bool ok = (xnb[i] >= 0) & ((unsigned)(xih[i] + l_kh) < (unsigned)g.H0) & ((unsigned)(xiw[i] + l_kw) < (unsigned)g.W0);
+                pg_dma16(rs0, sX + i * 1024, ok ? xbase[i] + toff : kOOB, 0);
+            }
+        } else if (SRC == SRC_1X1) {
 #pragma unroll
             for (int i = 0; i < XP; ++i) pg_dma16(rs0, sX + i * 1024, xbase[i], soff);
         } else if (SRC == SRC_PLAIN_ZERO) {
@@ -217,7 +285,10 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
         if (ls == 0 && has_bias && wave < BN / 64)        // the item's bias row rides with its first stage (4 B per lane, 64 channels per wave)
             pg_dma4(rsb, smem + BIAS_BASE + (l_item % D) * BIAS_BYTES + wave * 256, (unsigned)((lwk.tile_n * BN + wave * 64 + lane) * 4));
         ++issued;
-        if (SRC != SRC_1X1) {
+        if (SRC == SRC_ZEROINS_ZERO) {
+            l_cb += 64;
+            if (l_cb == g.C0) { l_cb = 0; if (++l_kw == l_ntb) { l_kw = 0; ++l_kh; } }
+        } else if (SRC != SRC_1X1) {
             l_cb += 64;
             if (l_cb == g.Cin) { l_cb = 0; if (++l_kw == g.KW) { l_kw = 0; ++l_kh; } }
         }
@@ -225,7 +296,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             ls = 0;
             ++l_item;
             lw += grid;
-            if (lw < q.total) { lwk = pg_work<BM, BN>(q, lw); if (lwk.nk > 0) setup_item(); }
+            if (lw < q.total) { lwk = pg_work<BM, BN, SRC>(q, lw); if (lwk.nk > 0) setup_item(); }
             else lwk.nk = 0;
         }
     };
@@ -246,7 +317,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
 
 #pragma unroll 1
     for (int cw = blockIdx.x; cw < q.total; cw += grid) {
-        const PGWork wk = pg_work<BM, BN>(q, cw);
+        const PGWork wk = pg_work<BM, BN, SRC>(q, cw);
         if (wk.nk == 0) continue;        // (cannot happen with the host's split arithmetic; the load cursor skips such items the same way)
         const int m0 = wk.tile_m * BM, n0 = wk.tile_n * BN;
 #pragma unroll
@@ -332,12 +403,36 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             // which makes hipcc's waitcnt pass alias-check it against the LDS-DMA writes in flight and emit s_waitcnt vmcnt(0) in front of it.
             constexpr int G8 = EN / 8;                                      // 16-byte groups per staged row
             const int nc0 = n0 + ch * EN;
+            if (SRC == SRC_ZEROINS_ZERO) {       // row m of the class -> output pixel (2 ci + ih0, 2 cj + iw0)
+                const PGClass k = pg_class(g, wk.cls);
+#pragma unroll
+                for (int id = tid; id < BM * G8; id += PG_THREADS) {
+                    const int row = id / G8, c8 = id - row * G8;
+                    const int m = m0 + row, n = nc0 + c8 * 8;
+                    if (m >= k.M || n >= p.ldy) continue;
+                    const int b_ = m / (k.IHc * k.IWc), rem = m - b_ * (k.IHc * k.IWc);
+                    const int ci = rem / k.IWc, cj = rem - ci * k.IWc;
+                    const int ih = 2 * ci + k.ih0, iw = 2 * cj + k.iw0;
+                    unsigned char* dst = (unsigned char*)p.y + (((size_t)(b_ * g.OH + ih) * g.OW + iw) * p.ldy + n) * 2;
+                    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(sC + row * CST + c8 * 16);
+                    if (q.zero_siblings) {
+                        const u32x4 z = {0u, 0u, 0u, 0u};
+                        const size_t dx = (size_t)p.ldy * 2, dyb = (size_t)g.OW * p.ldy * 2;
+                        if (iw + 1 < g.OW) *reinterpret_cast<u32x4*>(dst + dx) = z;
+                        if (ih + 1 < g.OH) {
+                            *reinterpret_cast<u32x4*>(dst + dyb) = z;
+                            if (iw + 1 < g.OW) *reinterpret_cast<u32x4*>(dst + dyb + dx) = z;
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int id = tid; id < BM * G8; id += PG_THREADS) {
                 const int row = id / G8, c8 = id - row * G8;
                 const int m = m0 + row, n = nc0 + c8 * 8;
                 if (m < g.M && n < p.ldy)                                   // ldy % 8 == 0
                     *reinterpret_cast<u32x4*>((unsigned char*)p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const u32x4*>(sC + row * CST + c8 * 16);
+            }
             }
             if (p.stats) {
                 // per-tile column sums of y and y^2 (of the rounded values) over the valid rows: PARTS interleaved row sets per column
@@ -392,14 +487,19 @@ static int pg_dispatch_src(const PGemmP& q, int src, hipStream_t s) {
         case SRC_1X1: return pg_launch<T16, BM, BN, SRC_1X1, D>(q, s);
         case SRC_PLAIN_ZERO: return pg_launch<T16, BM, BN, SRC_PLAIN_ZERO, D>(q, s);
         case SRC_PLAIN_REFLECT: return pg_launch<T16, BM, BN, SRC_PLAIN_REFLECT, D>(q, s);
+        case SRC_ZEROINS_ZERO: return pg_launch<T16, BM, BN, SRC_ZEROINS_ZERO, D>(q, s);
         default: return pg_launch<T16, BM, BN, SRC_UPCAT_REFLECT, D>(q, s);
     }
 }
 
 // The layers this kernel takes: bf16, every source a multiple of 64 channels (a stage is one filter tap x 64 channels), no zero insertion.
 bool pgemm_applicable(const Gather& g, int dtype, int ldy) {
-    if (!SDE_IS16(dtype) || g.mode == SDE_SRC_ZEROINS) return false;
+    if (!SDE_IS16(dtype)) return false;
     if (g.Cin % 64 || g.C0 % 64 || (g.mode == SDE_SRC_UPCAT && !g.reflect)) return false;
+    if (g.mode == SDE_SRC_ZEROINS) {          // data gradient of a stride-2 convolution: parity classes; either every class has a tap (K >= 2) or it is 1x1
+        if (g.reflect || g.stride != 1 || g.KH != g.KW || g.pad < 0) return false;
+        if (g.KH == 1 && g.pad != 0) return false;
+    }
     if (ldy % 8) return false;
     if ((long)g.Bn * g.IH * g.IW * (g.C0 > g.C1 ? g.C0 : g.C1) * 2L >= 0x7fffffffL) return false;      // 32-bit byte offsets
     return true;
@@ -407,6 +507,7 @@ bool pgemm_applicable(const Gather& g, int dtype, int ldy) {
 
 int pgemm_src_kind(const Gather& g) {
     if (g.mode == SDE_SRC_UPCAT) return SRC_UPCAT_REFLECT;
+    if (g.mode == SDE_SRC_ZEROINS) return SRC_ZEROINS_ZERO;
     if (g.KH == 1 && g.KW == 1 && g.pad == 0 && !g.reflect) return SRC_1X1;
     return g.reflect ? SRC_PLAIN_REFLECT : SRC_PLAIN_ZERO;
 }
@@ -439,6 +540,19 @@ int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s) {
     q.nk_total = p.g.Ktot / 64;
     q.nk_per = sde_cdiv(q.nk_total, p.ksplit);
     const int src = pgemm_src_kind(p.g);
+    q.zero_siblings = 0;
+    for (int c = 0; c < 4; ++c) q.cls_end[c] = 0;
+    if (src == SRC_ZEROINS_ZERO) {
+        int end = 0;
+        for (int c = 0; c < 4; ++c) {
+            const PGClass k = pg_class(p.g, c);
+            if (k.nta > 0 && k.ntb > 0) end += sde_cdiv(k.M, BM) * q.tiles_n;
+            q.cls_end[c] = end;
+        }
+        q.total = end;
+        q.zero_siblings = (p.g.KH == 1 && p.g.KW == 1) ? 1 : 0;
+        if (q.total == 0) return 0;
+    }
     return dtype == SDE_F16 ? pgemm_run_t<half_t>(q, tile, src, depth, s) : pgemm_run_t<bf16_t>(q, tile, src, depth, s);
 }
 

@@ -48,6 +48,11 @@ CASES = [
     ("upcat_256_1024_256", 1, 6, 10, 256, 1024, 256, 3, 1, 1, True, True, 1, 7064064),
     ("upcat_64_0_64", 2, 12, 20, 64, 0, 64, 3, 1, 1, True, True, 1, 7064064),
     ("5x5_64_64", 1, 12, 20, 64, 0, 64, 5, 1, 2, False, True, 0, 7064064),
+    # stride 2: the data gradient runs as four parity classes of output pixels (dense sub-convolutions over the taps that meet a real pixel)
+    ("3x3_s2_64_64_odd", 2, 13, 21, 64, 0, 64, 3, 2, 1, False, False, 0, 7064064),
+    ("5x5_s2_64_128", 1, 16, 24, 64, 0, 128, 5, 2, 2, False, True, 0, 7064064),
+    ("7x7_s2_64_64", 1, 17, 23, 64, 0, 64, 7, 2, 3, False, False, 0, 7064064),
+    ("1x1_s2_64_64_odd", 2, 13, 21, 64, 0, 64, 1, 2, 0, False, False, 0, 7064064),
     ("3x3_64_64_big_t128064", 2, 128, 256, 64, 0, 64, 3, 1, 1, False, False, 0, 7128064),
     ("3x3_128_256_t128128", 2, 24, 40, 128, 0, 256, 3, 1, 1, False, True, 1, 7128128),
     ("upcat_64_64_128_t128064", 2, 12, 20, 64, 64, 128, 3, 1, 1, True, True, 1, 7128064),
