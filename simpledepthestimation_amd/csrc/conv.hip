@@ -1348,6 +1348,7 @@ namespace sdeconv {
 bool pgemm_applicable(const Gather& g, int dtype, int ldy);
 int pgemm_tile(long M, int ldy);
 int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s);
+int pgemm_stats_rows(const Gather& g, int ldy, int depth);
 extern int g_pgemm_force_tile;
 }
 namespace {
@@ -1403,6 +1404,8 @@ static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const flo
     }
     if (use_pgemm(p.g, d->dtype, ldy)) {
         SDE_CHECK_ARG((p.ksplit - 1) * sde_cdiv(p.g.Ktot / 64, p.ksplit) < p.g.Ktot / 64, "sde_conv_fwd: empty K split");
+        // sde_conv_fwd_tiles_m does not know whether a workspace will be passed: a split layer's statistics slab has one row per 64 rows
+        SDE_CHECK_ARG(p.ksplit == 1 || sdeconv::pgemm_stats_rows(p.g, ldy, g_pgemm_depth) == sde_cdiv(p.g.M, 64), "sde_conv_fwd: split-K layer with per-workgroup statistics");
         sdeconv::pgemm_run(p, d->dtype, g_pgemm_depth, (hipStream_t)stream);
     } else if (use_halo(p.g, d->dtype, ldy)) {
         if (d->dtype == SDE_BF16) dispatch_halo<bf16_t>(p, (hipStream_t)stream); else dispatch_halo<half_t>(p, (hipStream_t)stream);
@@ -1449,7 +1452,7 @@ int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
     // number of M tiles the dispatcher will use (= rows of the BN-statistics slab)
     Gather g;
-    if (gather_of(d, g) == SDE_OK && use_pgemm(g, d->dtype, ldy)) return sde_cdiv(g.M, pgemm_tile(g.M, ldy) / 1000);
+    if (gather_of(d, g) == SDE_OK && use_pgemm(g, d->dtype, ldy)) return sdeconv::pgemm_stats_rows(g, ldy, g_pgemm_depth);
     if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return halo_tiles_m(g);
     const long M = (long)d->Bn * d->OH * d->OW;
     return sde_cdiv(M, pick_tile(M, ldy, d->KH * d->KW * (d->C0 + d->C1)) / 1000);

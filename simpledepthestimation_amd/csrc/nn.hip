@@ -112,20 +112,49 @@ __device__ __forceinline__ double half_wave_sum(double v) {
     return v;
 }
 
+// Column sums of a partial-sum slab [rows][width] for the 16 consecutive columns starting at col0, by one 1024-thread workgroup:
+// thread = (row lane tid / 16, column tid % 16); 64 rows are in flight per load and every row is one 64-byte segment, so the loads
+// coalesce (the previous form walked rows with a stride of the whole slab width per lane, 32 lanes per channel); 4 independent loads per
+// thread before the first add, i.e. 256 rows per round trip: a 2048-row slab is 8 round trips.  Double accumulation in a fixed order
+// (row lane, then the 64-way LDS sum): deterministic.  Result in sh[SLAB_RES + 0..15] after the trailing barrier; columns >= width read 0.
+constexpr int SLAB_T = 1024, SLAB_RL = SLAB_T / 16, SLAB_RES = SLAB_RL * 17, SLAB_SH = SLAB_RES + 16;
+__device__ __forceinline__ void slab_colsum16(const float* __restrict__ part, int rows, int width, int col0, double* sh /* [SLAB_SH] */) {
+    const int rl = threadIdx.x >> 4, e = threadIdx.x & 15;
+    const bool ok = col0 + e < width;
+    const float* src = part + col0 + e;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int t = rl;
+    if (ok) {
+        for (; t + 3 * SLAB_RL < rows; t += 4 * SLAB_RL) {
+            const float v0 = src[(size_t)t * width], v1 = src[(size_t)(t + SLAB_RL) * width], v2 = src[(size_t)(t + 2 * SLAB_RL) * width],
+                        v3 = src[(size_t)(t + 3 * SLAB_RL) * width];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; t < rows; t += SLAB_RL) a0 += src[(size_t)t * width];
+    }
+    sh[rl * 17 + e] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double tot = 0;
+        for (int i = 0; i < SLAB_RL; ++i) tot += sh[i * 17 + threadIdx.x];
+        sh[SLAB_RES + threadIdx.x] = tot;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // BatchNorm
 // ------------------------------------------------------------------------------------------------------------------
 // bnp layout: [4][C] = mean, rstd, scale (= gamma*rstd), shift (= beta - mean*scale)
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ part, int tiles, int C, float count, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(SLAB_T) bn_finalize_kernel(const float* __restrict__ part, int tiles, int C, float count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                                           float momentum, float eps, float* __restrict__ bnp) {
-    // 256 threads = 8 channels x 32 row lanes (tiles <= SDE_REDUCE_ROWS after the pre-reduction)
-    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
-    double s1 = 0, s2 = 0;
-    if (c < C)
-        for (int t = r; t < tiles; t += 32) { s1 += part[((size_t)t * C + c) * 2]; s2 += part[((size_t)t * C + c) * 2 + 1]; }
-    s1 = half_wave_sum(s1); s2 = half_wave_sum(s2);
-    if (c >= C || r != 0) return;
+    // one workgroup = 8 channels = 16 consecutive floats (sum, sum^2 interleaved) of every partial row
+    __shared__ double sh[SLAB_SH];
+    slab_colsum16(part, tiles, 2 * C, blockIdx.x * 16, sh);
+    const int c = blockIdx.x * 8 + threadIdx.x;
+    if (threadIdx.x >= 8 || c >= C) return;
+    const double s1 = sh[SLAB_RES + 2 * threadIdx.x], s2 = sh[SLAB_RES + 2 * threadIdx.x + 1];
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0) var = 0;
@@ -288,14 +317,13 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // coef layout [2][C]: mean(dz), mean(dz*xhat); also dgamma (+)=, dbeta (+)=
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float count, float* __restrict__ dgamma,
+__global__ void __launch_bounds__(SLAB_T) bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, float count, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
-    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
-    double s1 = 0, s2 = 0;
-    if (c < C)
-        for (int t = r; t < nblk; t += 32) { s1 += part[((size_t)t * C + c) * 2]; s2 += part[((size_t)t * C + c) * 2 + 1]; }
-    s1 = half_wave_sum(s1); s2 = half_wave_sum(s2);
-    if (c >= C || r != 0) return;
+    __shared__ double sh[SLAB_SH];
+    slab_colsum16(part, nblk, 2 * C, blockIdx.x * 16, sh);
+    const int c = blockIdx.x * 8 + threadIdx.x;
+    if (threadIdx.x >= 8 || c >= C) return;
+    const double s1 = sh[SLAB_RES + 2 * threadIdx.x], s2 = sh[SLAB_RES + 2 * threadIdx.x + 1];
     coef[c] = (float)(s1 / count); coef[C + c] = (float)(s2 / count);
     dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
@@ -469,14 +497,13 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ part, int nblk, int ld, int C, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
-    double s = 0;
-    if (c < C)
-        for (int t = r; t < nblk; t += 32) s += part[(size_t)t * ld + c];
-    s = half_wave_sum(s);
-    if (c >= C || r != 0) return;
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+__global__ void __launch_bounds__(SLAB_T) colsum_finalize_kernel(const float* __restrict__ part, int nblk, int ld, int C, float* __restrict__ out, int accumulate) {
+    __shared__ double sh[SLAB_SH];
+    slab_colsum16(part, nblk, ld, blockIdx.x * 16, sh);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= C) return;
+    const double sv = sh[SLAB_RES + threadIdx.x];
+    out[c] = accumulate ? out[c] + (float)sv : (float)sv;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -943,9 +970,8 @@ __global__ void loss_scale_update_kernel(float* __restrict__ state, float growth
 // If the slab has more than SDE_REDUCE_ROWS rows, fold it into SDE_REDUCE_ROWS rows stored right behind it (the caller
 // allocates rows + SDE_REDUCE_ROWS rows).  Returns the pointer / row count the finalize kernel should read.
 const float* pre_reduce(const float* part, int& rows, int width, hipStream_t s) {
-    // the finalize kernels read rows with 32 independent lanes, so slabs up to SDE_PRE_REDUCE_ROWS rows (default 512: 16 loads per lane) need
-    // no extra launch; 2048 measured slower (the 64 serial loads per lane cost more than the extra launch)
-    constexpr int thr = 512;
+    // only slabs taller than this take the extra launch: the finalize kernels keep 256 rows in flight per round trip
+    constexpr int thr = 4096;
     if (rows <= thr) return part;
     float* out = const_cast<float*>(part) + (size_t)rows * width;
     const int chunk = (rows + SDE_REDUCE_ROWS - 1) / SDE_REDUCE_ROWS;
@@ -991,7 +1017,7 @@ int sde_bn_finalize(const float* part, int tiles, int C, long count, const float
     SDE_CHECK_ARG(part && gamma && beta && bnp && tiles > 0 && C > 0 && count > 0, "sde_bn_finalize: bad argument");
     int rows = tiles;
     const float* src = pre_reduce(part, rows, 2 * C, (hipStream_t)stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, src, rows, C, (float)count, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(SLAB_T), 0, (hipStream_t)stream, src, rows, C, (float)count, gamma, beta, running_mean,
                        running_var, momentum, eps, bnp);
     SDE_CHECK_LAUNCH("sde_bn_finalize");
     return SDE_OK;
@@ -1046,7 +1072,7 @@ int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const voi
     SDE_CHECK_LAUNCH("sde_bn_bwd/reduce");
     int rows = nblk;
     const float* src = pre_reduce(part, rows, 2 * C, s);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(256), 0, s, src, rows, C, (float)M, dgamma, dbeta, accumulate_params, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(SLAB_T), 0, s, src, rows, C, (float)M, dgamma, dbeta, accumulate_params, coef);
     SDE_CHECK_LAUNCH("sde_bn_bwd/finalize");
     const int nb = grid_for(M * (C / V));
     const void* dz = gm ? gm : dout;
@@ -1103,7 +1129,7 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
     if (dbias) {
         int rows = nblk;
         const float* src = pre_reduce(part, rows, C, s);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sde_cdiv(Cbias, 8)), dim3(256), 0, s, src, rows, C, Cbias, dbias, accumulate);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sde_cdiv(Cbias, 16)), dim3(SLAB_T), 0, s, src, rows, C, Cbias, dbias, accumulate);
         SDE_CHECK_LAUNCH("sde_act_bwd_bias/finalize");
     }
     return SDE_OK;

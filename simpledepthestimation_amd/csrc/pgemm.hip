@@ -81,6 +81,11 @@ struct PGemmP {
     // inserted zero) gradient pixel -- so every class is a dense GEMM with K = (its taps) x C instead of all KH*KW taps at 1/4 density.
     int cls_end[4];                     // exclusive prefix sums of the classes' tile counts (tiles_m(c) * tiles_n)
     int zero_siblings;                  // 1x1 kernels: only class 0 has a tap; its tiles also write the zeros of the other three pixels of each 2x2 cell
+    // BatchNorm statistics, many tiles per workgroup: when (grid / 8) % tiles_n == 0 every tile of a workgroup has the same tile_n (work w ->
+    // logical base(xcd) + (w >> 3), and w advances by grid), so the workgroup keeps its (sum, sum^2) partials in registers over all its tiles and
+    // writes ONE slab row at the end: grid / tiles_n rows instead of tiles_m (768 instead of 5760 for the 96x320 layers), no per-tile LDS
+    // combine.  Row of workgroup bid = (bid & 7) * (grid / 8 / tiles_n) + (bid >> 3) / tiles_n (dense per tile_n; see pgemm_stats_rows).
+    int stats_acc;
 };
 
 // One work item: tile (tile_m, tile_n), K stages [s_begin, s_begin + nk)
@@ -311,6 +316,10 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
 
     pg_f32x16 acc[FN][FM];
     int consumed = 0, c_item = 0;        // stages consumed / items finished by the compute side
+    float st1[NCH], st2[NCH];            // stats_acc: this thread's (channel tid % EN, row set tid / EN) sums over all tiles of the workgroup
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) st1[ch] = st2[ch] = 0.f;
+    int st_n0 = 0;
 
 #pragma unroll 1
     for (int i = 0; i < D - 1; ++i) issue_next();
@@ -445,6 +454,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
                     const float t = (float)*reinterpret_cast<const T16*>(sC + r * CST + c * 2);
                     s1 += t; s2 += t * t;
                 }
+                if (q.stats_acc) { st1[ch] += s1; st2[ch] += s2; st_n0 = n0; continue; }
                 pg_lds_store8(sC_a + BM * CST + (part * EN + c) * 8, __builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -461,11 +471,43 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
         // the next stage's barrier orders these LDS reads before the slot's refill
     }
     pg_wait_vmcnt<0>();      // nothing may be in flight into LDS when the workgroup ends
+    if (p.stats && q.stats_acc) {
+        constexpr int PARTS = PG_THREADS / EN;
+        float* red = reinterpret_cast<float*>(smem);                       // [NCH][PARTS][EN][2]
+        __builtin_amdgcn_s_barrier();                                      // every wave is done with the ring
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+            pg_lds_store8(pg_lds_addr(smem) + (ch * PG_THREADS + tid) * 8, __builtin_bit_cast(unsigned, st1[ch]), __builtin_bit_cast(unsigned, st2[ch]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int row = (blockIdx.x & 7) * ((grid >> 3) / q.tiles_n) + (blockIdx.x >> 3) / q.tiles_n;
+        for (int id = tid; id < BN; id += PG_THREADS) {
+            const int ch = id / EN, c = id - ch * EN;
+            if (st_n0 + id >= p.Cout) continue;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int z = 0; z < PARTS; ++z) { a += red[((ch * PARTS + z) * EN + c) * 2]; b += red[((ch * PARTS + z) * EN + c) * 2 + 1]; }
+            p.stats[((size_t)row * p.Cout + st_n0 + id) * 2 + 0] = a;
+            p.stats[((size_t)row * p.Cout + st_n0 + id) * 2 + 1] = b;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
+// Workgroups of a full launch: as many as fit per CU by LDS (stage ring + bias ring), at most 4, times 256 CUs.
+static int pg_grid_max(int BM, int BN, int D) {
+    const int lds = D * ((BM + BN) * PG_STAGE_K_BYTES + BN * 4);
+    const int per_cu = (160 * 1024) / lds;
+    return 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+}
+
+static bool pg_stats_acc(int tiles_n, int tiles_mn, int ksplit, int src, int BM, int BN, int D) {
+    const int grid = pg_grid_max(BM, BN, D);
+    return ksplit == 1 && src != SRC_ZEROINS_ZERO && tiles_mn > grid && (grid >> 3) % tiles_n == 0;
+}
+
 template <typename T16, int BM, int BN, int SRC, int D>
 static int pg_launch(const PGemmP& q, hipStream_t s) {
     constexpr int lds = D * ((BM + BN) * PG_STAGE_K_BYTES + BN * 4);      // stage ring + bias ring
@@ -474,8 +516,7 @@ static int pg_launch(const PGemmP& q, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm_kernel<T16, BM, BN, SRC, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    const int per_cu = (160 * 1024) / lds;
-    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    int grid = pg_grid_max(BM, BN, D);
     if (grid > q.total) grid = q.total;
     hipLaunchKernelGGL((pgemm_kernel<T16, BM, BN, SRC, D>), dim3(grid), dim3(PG_THREADS), lds, s, q);
     return 0;
@@ -522,6 +563,8 @@ int pgemm_tile(long M, int ldy) {
     return g_pgemm_force_tile ? g_pgemm_force_tile : 64064;
 }
 
+static int pg_depth(int tile, int depth) { return tile == 128128 || depth == 3 ? 3 : 4; }      // the ring depth pgemm_run_t instantiates
+
 template <typename T16>
 static int pgemm_run_t(const PGemmP& q, int tile, int src, int depth, hipStream_t s) {
     if (tile == 128128) return pg_dispatch_src<T16, 128, 128, 3>(q, src, s);
@@ -541,6 +584,7 @@ int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s) {
     q.nk_per = sde_cdiv(q.nk_total, p.ksplit);
     const int src = pgemm_src_kind(p.g);
     q.zero_siblings = 0;
+    q.stats_acc = p.stats && pg_stats_acc(q.tiles_n, q.tiles_mn, p.ksplit, src, BM, BN, pg_depth(tile, depth)) ? 1 : 0;
     for (int c = 0; c < 4; ++c) q.cls_end[c] = 0;
     if (src == SRC_ZEROINS_ZERO) {
         int end = 0;
@@ -554,6 +598,16 @@ int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s) {
         if (q.total == 0) return 0;
     }
     return dtype == SDE_F16 ? pgemm_run_t<half_t>(q, tile, src, depth, s) : pgemm_run_t<bf16_t>(q, tile, src, depth, s);
+}
+
+// Rows of the BatchNorm-statistics slab pgemm_run writes for this layer (split-K layers: the finish kernel's, one per 64 rows).
+int pgemm_stats_rows(const Gather& g, int ldy, int depth) {
+    const int tile = pgemm_tile(g.M, ldy);
+    const int BM = tile / 1000, BN = tile % 1000;
+    depth = pg_depth(tile, depth);
+    const int tiles_n = sde_cdiv(ldy, BN), tiles_mn = sde_cdiv(g.M, BM) * tiles_n;
+    if (pg_stats_acc(tiles_n, tiles_mn, 1, pgemm_src_kind(g), BM, BN, depth)) return pg_grid_max(BM, BN, depth) / tiles_n;
+    return sde_cdiv(g.M, BM);
 }
 
 }  // namespace sdeconv
