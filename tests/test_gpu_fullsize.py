@@ -1,0 +1,212 @@
+"""GPU parity at BASELINE.json's full size (bs=12, 192x640, ResNet-50) through the dispatch the bench ships -- nothing forced.
+
+  * every distinct convolution of the Supervised ResNet-50 model (recorded from one forward pass of the model itself), bf16, at the
+    full batch: forward, data gradient, skip gradient and weight gradient against torch-CPU fp32 convolution on the bf16-rounded
+    operands, plus the variant code the dispatcher chose for it (the table is printed with -s; profiles/r02_layer_variants.txt);
+  * the fp32 HIP path against the CPU oracle at the full size (loss, depth, every gradient tensor);
+  * the bench's own configuration -- bf16, captured hipGraph, replayed -- against the fp32 HIP path: loss and update direction.
+
+Reference: resnet_encoder.py:L88-99, depth_decoder.py:L21-110, sup_depth_model.py (forward / losses).
+"""
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import models as OM
+from oracle.gen_golden import sup_batch
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+B, H, W = 12, 192, 640
+
+
+def make_cfg(enc, dtype):
+    from simpledepthestimation_amd.config import get_project_cfg
+    cfg = get_project_cfg("Supervised")
+    cfg.MODEL.DEPTH_NET.ENCODER_NAME = str(enc)
+    cfg.MODEL.COMPUTE_DTYPE = dtype
+    cfg.MODEL.DEVICE = dev
+    return cfg
+
+
+def build(enc, sd, dtype):
+    from simpledepthestimation_amd.modeling import build_model
+    m = build_model(make_cfg(enc, dtype))
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def clone_batch(b):
+    return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def layer_table():
+    """The distinct convolutions of one forward pass of the bf16 ResNet-50 model at 192x640 (shapes per image; the batch is set by the test)."""
+    from simpledepthestimation_amd.hip import nn as HN
+    sd = OM.init_state_dict(50, seed=5)
+    model = build(50, sd, "bf16").train()
+    seen, orig = {}, HN.conv2d
+
+    def spy(x, weight, bias=None, stride=1, pad=0, reflect=False, act=0, skip=None, upsample=False, bn_stats=False, owner=None):
+        key = (x.shape[1], x.shape[2], x.shape[3], 0 if skip is None else skip.shape[3], weight.shape[0], weight.shape[2], int(stride), int(pad),
+               bool(reflect), bias is not None, int(act), bool(upsample), bool(bn_stats))
+        seen[key] = seen.get(key, 0) + 1
+        return orig(x, weight, bias, stride, pad, reflect, act, skip, upsample, bn_stats, owner)
+
+    HN.conv2d = spy
+    try:
+        with torch.no_grad():
+            model(clone_batch(sup_batch(1, H, W, 3)))
+    finally:
+        HN.conv2d = orig
+    assert len(seen) >= 25, len(seen)
+    return sorted(seen.items())
+
+
+def test_every_resnet50_layer_at_full_batch_unforced(layer_table):
+    from simpledepthestimation_amd.hip import lib as L
+    from simpledepthestimation_amd.hip import nn as NN
+    rows, variants = [], set()
+    for li, (key, count) in enumerate(layer_table):
+        h, w_, C0, C1, Cout, k, stride, pad, reflect, has_bias, act, upcat, bn_stats = key
+        g = torch.Generator().manual_seed(100 + li)
+        x0 = torch.randn(B, C0, h, w_, generator=g).bfloat16().float()
+        x1 = torch.randn(B, C1, 2 * h, 2 * w_, generator=g).bfloat16().float() if C1 else None
+        Cin = C0 + C1
+        wt = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).bfloat16().float()
+        bias = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
+        xr = x0.clone().requires_grad_(True)
+        x1r = x1.clone().requires_grad_(True) if C1 else None
+        wr = wt.clone().requires_grad_(True)
+        xin = xr
+        if upcat:
+            up = F.interpolate(xr, scale_factor=2, mode="nearest")
+            xin = torch.cat([up, x1r], 1) if C1 else up
+        if reflect:
+            xin = F.pad(xin, (pad, pad, pad, pad), mode="reflect")
+        br = bias.clone().requires_grad_(True) if has_bias else None
+        yr = F.conv2d(xin, wr, br, stride, 0 if reflect else pad)
+        if act == 1:
+            yr = F.elu(yr)
+        gy = torch.randn(yr.shape, generator=g).bfloat16().float()
+        yr.backward(gy)
+
+        def nhwc(t):
+            return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+
+        xd = nhwc(x0).requires_grad_(True)
+        x1d = nhwc(x1).requires_grad_(True) if C1 else None
+        wd = wt.clone().to(dev).requires_grad_(True)
+        bd = bias.clone().to(dev).requires_grad_(True) if has_bias else None
+        res = NN.conv2d(xd, wd, bd, stride=stride, pad=pad, reflect=reflect, act=act, skip=x1d, upsample=upcat, bn_stats=bn_stats)
+        y, stats = res if isinstance(res, tuple) else (res, None)
+        d = NN._desc(xd, x1d, NN.SRC_UPCAT if upcat else NN.SRC_PLAIN, k, k, stride, pad, reflect, 2 * h if upcat else h, 2 * w_ if upcat else w_,
+                     y.shape[1], y.shape[2])
+        variant = L.lib().sde_conv_fwd_variant(ctypes.byref(d), y.shape[3])
+        variants.add(variant // 1000000)
+        gyd = nhwc(gy)
+        y.backward(gyd if y.shape[3] == Cout else F.pad(gyd, (0, y.shape[3] - Cout)))
+        torch.cuda.synchronize()
+        name = f"{'up' if upcat else ''}{k}x{k}s{stride}{'r' if reflect else ''} {C0}+{C1}->{Cout} @{yr.shape[2]}x{yr.shape[3]}"
+        e_y = rel(y[..., :Cout].float().permute(0, 3, 1, 2), yr)
+        e_dx = rel(xd.grad.float().permute(0, 3, 1, 2), xr.grad)
+        e_dw = rel(wd.grad, wr.grad)
+        rows.append((name, count, variant, e_y, e_dx, e_dw))
+        assert e_y < 6e-3, f"{name}: y relative L2 {e_y:.3e} (variant {variant})"
+        # the first convolution's input is the image: its data gradient is not computed by the model either, but the op supports it
+        assert e_dx < 6e-3, f"{name}: dX relative L2 {e_dx:.3e} (variant {variant})"
+        assert e_dw < 2e-3, f"{name}: dW relative L2 {e_dw:.3e}"
+        if C1:
+            e_ds = rel(x1d.grad.float().permute(0, 3, 1, 2), x1r.grad)
+            assert e_ds < 6e-3, f"{name}: dSkip relative L2 {e_ds:.3e}"
+        if has_bias:
+            assert rel(bd.grad, br.grad) < 2e-3, name
+        if stats is not None:
+            yy = y[..., :Cout].double().reshape(-1, Cout)
+            ref = torch.stack([yy.sum(0), (yy * yy).sum(0)], 1).cpu()
+            tot = stats[: stats.shape[0] - NN.REDUCE_ROWS].double().sum(0).cpu()
+            assert ((tot - ref).abs() <= 1e-3 * ref.abs() + 1e-2).all(), f"{name}: BatchNorm partial sums"
+    print("\nlayer (per image)                              uses  variant   err(y)    err(dX)   err(dW)")
+    for name, count, variant, e_y, e_dx, e_dw in rows:
+        print(f"{name:46s} {count:4d}  {variant:8d}  {e_y:.2e}  {e_dx:.2e}  {e_dw:.2e}")
+    # the shipped dispatch uses the persistent LDS-DMA GEMM (7......), the LDS-halo 3x3 kernel (3......) and the register-staged kernel (< 1000000)
+    assert {7, 3, 0} <= variants, variants
+
+
+def _oracle_grads(sd, batch, dt):
+    sdo = {k: (v.clone().to(dt).requires_grad_(True) if v.is_floating_point() and "running" not in k and "pixel" not in k
+               else (v.clone().to(dt) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+    b = {k: (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    out = OM.supervised_forward(sdo, b, 50)
+    out["silog_loss"].backward()
+    return out, sdo
+
+
+def test_fp32_step_at_full_size_vs_cpu_oracle():
+    """north_star tolerance at BASELINE configs[1]'s size: depth within 1e-4 relative.  Gradients per tensor by relative L2 against the
+    oracle run in float64: fifty BatchNorm'd layers at random init are ill-conditioned enough that the oracle's OWN fp32 run differs from
+    its fp64 run by ~1e-2 on some layer-4 tensors (summation order alone), so a tensor passes when the HIP fp32 gradient is as close to
+    the fp64 one as the CPU fp32 gradient is (x4), or within 2e-3 outright."""
+    sd = OM.init_state_dict(50, seed=21)
+    batch = sup_batch(B, H, W, 6)
+    o64, g64 = _oracle_grads(sd, batch, torch.float64)
+    o32, g32 = _oracle_grads(sd, batch, torch.float32)
+    m = build(50, sd, "fp32").train()
+    o = m(clone_batch(batch))
+    o["silog_loss"].backward()
+    assert abs(o["silog_loss"].item() - o64["silog_loss"].item()) < 1e-4 * abs(o64["silog_loss"].item())
+    d, dr = o["depth_pred"][0].detach().cpu().double(), o64["depth_pred"][0].detach()
+    assert ((d - dr).abs() / dr.abs()).max().item() < 1e-4
+    worst, worst_cpu, bad = (0.0, ""), (0.0, ""), []
+    for n, p in m.named_parameters():
+        if ".fc." in n:
+            assert p.grad is None
+            continue
+        e = rel(p.grad, g64[n].grad)
+        e_cpu = rel(g32[n].grad, g64[n].grad)
+        worst = max(worst, (e, n))
+        worst_cpu = max(worst_cpu, (e_cpu, n))
+        if e > max(2e-3, 4 * e_cpu):
+            bad.append((n, e, e_cpu))
+    print(f"fp32 full size vs fp64 oracle: worst HIP tensor {worst}; worst CPU-fp32 tensor {worst_cpu}")
+    assert not bad, bad[:5]
+
+
+def test_bench_configuration_bf16_graph_replay_tracks_fp32():
+    """The configuration bench.py times (bf16, captured hipGraph, side stream, deferred weight-gradient reduction), three replayed steps,
+    against the fp32 HIP path stepping eagerly from the same weights on the same batch."""
+    from simpledepthestimation_amd.engine.trainer import supervised_trainer
+    sd = OM.init_state_dict(50, seed=22)
+    batch = {k: v.to(dev) for k, v in sup_batch(B, H, W, 8).items()}
+    res = {}
+    for dtype, graph in (("fp32", False), ("bf16", True)):
+        model = build(50, sd, dtype).train()
+        tr = supervised_trainer(model, make_cfg(50, dtype), use_graph=graph)
+        p0 = tr.pflat.clone()
+        losses = [float(tr.step(clone_batch(batch))["silog_loss"])]
+        g1 = tr.gflat.double().cpu()                          # the first step's gradient (zeroed at the start of the next step)
+        losses += [float(tr.step(clone_batch(batch))["silog_loss"]) for _ in range(2)]
+        res[dtype] = (losses, (tr.pflat - p0).double().cpu(), g1)
+        del tr, model
+        torch.cuda.empty_cache()
+    l32, u32, g32 = res["fp32"]
+    l16, u16, g16 = res["bf16"]
+    print(f"losses fp32 {l32} bf16 {l16}")
+    assert all(math.isfinite(v) for v in l16)
+    for a, b in zip(l16, l32):
+        assert abs(a - b) < 3e-2 * abs(b), (l16, l32)
+    assert l16[-1] < l16[0] and l32[-1] < l32[0]            # both descend on the repeated batch
+    assert torch.isfinite(g16).all()
+    cos_g = float((g16 @ g32) / (g16.norm() * g32.norm()))
+    cos_u = float((u16 @ u32) / (u16.norm() * u32.norm()))        # Adam's first updates are ~ lr * sign(g): a much noisier quantity
+    print(f"cosine(bf16 graph, fp32 eager): first gradient {cos_g:.4f}, parameter update over 3 steps {cos_u:.4f}")
+    assert cos_g > 0.9 and cos_u > 0.5, (cos_g, cos_u)
