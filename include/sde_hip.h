@@ -178,6 +178,8 @@ int sde_conv_set_halo_min_blocks(int min_blocks);
 #define SDE_OPT_PGEMM_TILE 4   /* force its tile: 64064, 128064, 128128; 0 (default) = chosen per layer */
 #define SDE_OPT_SPLITK 5       /* 1 (default): small-M, long-K layers cut K into up to 8 ranges (sde_conv_fwd_ws); 0: never */
 #define SDE_OPT_WGRAD_BLOCKS 6 /* workgroup target of the weight-gradient GEMM's pixel splits (default 256 = one per CU) */
+#define SDE_OPT_WGRAD_HALO 7   /* 1 (default): the 3x3 stride-1 layers with <= 96 input and <= 32 output channels take the LDS-halo weight-gradient
+                                  kernel (csrc/wgrad_halo.hip); 0: the generic kernel */
 int sde_conv_set_option(int key, int value);
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).

@@ -38,7 +38,11 @@ dt = torch.bfloat16
 dev = "cuda"
 print("lib:", L.LIB_PATH)
 print(f"{'shape':20s} {'fwd us':>8s} {'TF/s':>7s} {'dgrad us':>9s} {'TF/s':>7s} {'wgrad us':>9s} {'TF/s':>7s}")
+FILTER = os.environ.get("MB_FILTER")          # substring of the shape name
+STATS = bool(int(os.environ.get("MB_STATS", "0")))   # forward with the BatchNorm partial sums, as the encoder layers run
 for name, B, H, W, Cin, Cout, k, s, p, refl, C1 in SHAPES:
+    if FILTER and FILTER not in name:
+        continue
     g = torch.Generator().manual_seed(0)
     Cp = (Cin + 7) // 8 * 8
     x = torch.randn(B, H, W, Cp, generator=g).to(dt).to(dev)
@@ -47,13 +51,16 @@ for name, B, H, W, Cin, Cout, k, s, p, refl, C1 in SHAPES:
     w = (torch.randn(Cout, Cin + C1, k, k, generator=g) / math.sqrt((Cin + C1) * k * k)).to(dev).requires_grad_(True)
     xg = x.clone().requires_grad_(Cin >= 8)
     sg = skip.clone().requires_grad_(True) if skip is not None else None
-    y = HN.conv2d(xg, w, None, stride=s, pad=p, reflect=refl, skip=sg, upsample=up)
+    def fwd():
+        r = HN.conv2d(xg, w, None, stride=s, pad=p, reflect=refl, skip=sg, upsample=up, bn_stats=STATS)
+        return r[0] if isinstance(r, tuple) else r
+    y = fwd()
     gy = torch.randn_like(y)
     res = {}
     for _ in range(3):
         L.PROFILE = []
         for _ in range(5):
-            y = HN.conv2d(xg, w, None, stride=s, pad=p, reflect=refl, skip=sg, upsample=up)
+            y = fwd()
             y.backward(gy)
             w.grad = None
         torch.cuda.synchronize()

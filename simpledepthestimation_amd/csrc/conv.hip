@@ -1349,6 +1349,10 @@ bool pgemm_applicable(const Gather& g, int dtype, int ldy);
 int pgemm_tile(long M, int ldy);
 int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s);
 int pgemm_stats_rows(const Gather& g, int ldy, int depth);
+// halo weight gradient of the small-channel 3x3 layers (wgrad_halo.hip)
+bool whalo_applicable(const Gather& g, int dtype, int Cout, int ldd);
+int whalo_splits(const Gather& g, int Cout);
+int whalo_run(const Gather& g, int dtype, const void* dy, int Cout, int ldd, float* slab, int splits, hipStream_t s);
 extern int g_pgemm_force_tile;
 }
 namespace {
@@ -1458,7 +1462,14 @@ int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
     return sde_cdiv(M, pick_tile(M, ldy, d->KH * d->KW * (d->C0 + d->C1)) / 1000);
 }
 
+int g_wgrad_halo = 1;       // SDE_OPT_WGRAD_HALO
+static bool use_whalo(const Gather& g, int dtype, int Cout, int ldd) { return g_wgrad_halo && sdeconv::whalo_applicable(g, dtype, Cout, ldd); }
+
 int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
+    {
+        Gather g;
+        if (fill_gather(d, g, "sde_conv_wgrad_splits") == SDE_OK && use_whalo(g, d->dtype, Cout, 8)) return sdeconv::whalo_splits(g, Cout);
+    }
     const long M = (long)d->Bn * d->OH * d->OW;
     const int Ktot = d->KH * d->KW * (d->C0 + d->C1);
     const long tiles = (long)sde_cdiv(Cout, wgrad_bmg(Cout)) * sde_cdiv(Ktot, 128);
@@ -1481,6 +1492,14 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     const int V = SDE_IS16(d->dtype) ? 8 : 4;
     SDE_CHECK_ARG(Cout > 0 && ldd >= Cout && ldd % V == 0, "sde_conv_wgrad: bad Cout=%d ldd=%d", Cout, ldd);
     SDE_CHECK_ARG(splits >= 1, "sde_conv_wgrad: bad splits=%d", splits);
+    if (use_whalo(p.g, d->dtype, Cout, ldd)) {
+        SDE_CHECK_ARG(splits == sdeconv::whalo_splits(p.g, Cout), "sde_conv_wgrad: splits=%d, this layer needs sde_conv_wgrad_splits() = %d", splits,
+                      sdeconv::whalo_splits(p.g, Cout));
+        sdeconv::whalo_run(p.g, d->dtype, dy, Cout, ldd, slab, splits, s);
+        SDE_CHECK_LAUNCH("sde_conv_wgrad (halo)");
+        g = p.g;
+        return SDE_OK;
+    }
     const int BR = SDE_IS16(d->dtype) ? 64 : 32;
     int rps = sde_cdiv(p.g.M, splits);
     rps = sde_cdiv(rps, BR) * BR;
@@ -1603,7 +1622,7 @@ int sde_conv_set_option(int key, int value) {
         return old;
     }
     int* slot = key == SDE_OPT_PGEMM ? &g_use_pgemm : key == SDE_OPT_PGEMM_DEPTH ? &g_pgemm_depth : key == SDE_OPT_PGEMM_3X3 ? &g_pgemm_3x3 :
-                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : nullptr;
+                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : nullptr;
     SDE_CHECK_ARG(slot, "sde_conv_set_option: unknown key %d", key);
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_DEPTH || value == 3 || value == 4, "sde_conv_set_option: ring depth must be 3 or 4");
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_TILE || value == 0 || value == 64064 || value == 128064 || value == 128128, "sde_conv_set_option: bad tile %d", value);

@@ -28,6 +28,9 @@ namespace sdeconv {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 pg_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float pg_f32x16;
+typedef __attribute__((ext_vector_type(4))) float pg_f32x4;
+typedef __attribute__((ext_vector_type(2))) float pg_f32x2;
+template <int V> struct PgIC { static constexpr int value = V; };
 typedef __attribute__((address_space(3))) void pg_lds_void;
 
 constexpr int PG_THREADS = 256;
@@ -52,6 +55,9 @@ template <> struct PgType<bf16_t> {
         v2 v = {(__bf16)a, (__bf16)b};
         return __builtin_bit_cast(unsigned, v);
     }
+    static __device__ __forceinline__ pg_f32x2 unpack2(unsigned u) {      // two stored values -> fp32 (exact)
+        return pg_f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+    }
 };
 template <> struct PgType<half_t> {
     typedef __attribute__((ext_vector_type(8))) _Float16 frag;
@@ -60,6 +66,11 @@ template <> struct PgType<half_t> {
         typedef __attribute__((ext_vector_type(2))) _Float16 v2;
         v2 v = {(_Float16)a, (_Float16)b};
         return __builtin_bit_cast(unsigned, v);
+    }
+    static __device__ __forceinline__ pg_f32x2 unpack2(unsigned u) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+        const v2 v = __builtin_bit_cast(v2, u);
+        return pg_f32x2{(float)v[0], (float)v[1]};
     }
 };
 
@@ -70,6 +81,11 @@ __device__ __forceinline__ unsigned pg_lds_addr(const void* p) { return (unsigne
 __device__ __forceinline__ void pg_lds_store8(unsigned addr, unsigned a, unsigned b) {
     pg_u32x2 v = {a, b};
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void pg_lds_store16(unsigned addr, float a, float b, float c, float d) {
+    const pg_f32x4 v = {a, b, c, d};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 struct PGemmP {
@@ -86,6 +102,9 @@ struct PGemmP {
     // writes ONE slab row at the end: grid / tiles_n rows instead of tiles_m (768 instead of 5760 for the 96x320 layers), no per-tile LDS
     // combine.  Row of workgroup bid = (bid & 7) * (grid / 8 / tiles_n) + (bid >> 3) / tiles_n (dense per tile_n; see pgemm_stats_rows).
     int stats_acc;
+    // Work decode without divisions (the short-K layers spend more issue slots on per-tile bookkeeping than on MFMAs): under the same
+    // condition -- one K range, (grid / 8) % tiles_n == 0 -- the next item of a workgroup is (tile_m + tm_step, same tile_n).
+    int fast, tm_step;
 };
 
 // One work item: tile (tile_m, tile_n), K stages [s_begin, s_begin + nk)
@@ -132,6 +151,13 @@ __device__ __forceinline__ PGWork pg_work(const PGemmP& q, int w) {
     r.nk = (e < q.nk_total ? e : q.nk_total) - r.s_begin;
     if (r.nk < 0) r.nk = 0;
     return r;
+}
+
+// the item `grid` work indices after item wk (index w + grid < total)
+template <int BM, int BN, int SRC>
+__device__ __forceinline__ PGWork pg_next(const PGemmP& q, const PGWork& wk, int w_next) {
+    if (q.fast) { PGWork r = wk; r.tile_m += q.tm_step; return r; }
+    return pg_work<BM, BN, SRC>(q, w_next);
 }
 
 template <typename T16, int BM, int BN, int SRC, int D>
@@ -209,6 +235,16 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             l_cb = 0; l_kh = 0; l_kw = 0;         // here: tap COUNTERS ta, tb inside the class
             return;
         }
+        if (SRC == SRC_1X1 && g.stride == 1) {       // output pixel m IS input pixel m: no coordinates needed
+#pragma unroll
+            for (int i = 0; i < XP; ++i) {
+                const int row = wave * (BM / 4) + i * 8 + drow;
+                const int chunk = dslot ^ ((row >> 1) & 7);
+                const int m = m0 + row;
+                xnb[i] = 0; xih[i] = 0; xiw[i] = 0;
+                xbase[i] = m < g.M ? (unsigned)(m * g.C0 * 2 + chunk * 16) : kOOB;
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int row = wave * (BM / 4) + i * 8 + drow;
@@ -226,12 +262,14 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             else
                 xbase[i] = (unsigned)(chunk * 16);
         }
+        if (!(q.fast && l_item > 0)) {           // fast decode: tile_n never changes
 #pragma unroll
-        for (int i = 0; i < WP; ++i) {
-            const int row = wave * (BN / 4) + i * 8 + drow;
-            const int chunk = dslot ^ ((row >> 1) & 7);
-            const int n = n0 + row;
-            woff[i] = n < p.ldy ? (unsigned)(n * g.Ktot * 2 + chunk * 16) : kOOB;
+            for (int i = 0; i < WP; ++i) {
+                const int row = wave * (BN / 4) + i * 8 + drow;
+                const int chunk = dslot ^ ((row >> 1) & 7);
+                const int n = n0 + row;
+                woff[i] = n < p.ldy ? (unsigned)(n * g.Ktot * 2 + chunk * 16) : kOOB;
+            }
         }
         if (SRC != SRC_1X1) {
             const int k = lwk.s_begin * 64;
@@ -240,6 +278,11 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
         }
     };
     if (lwk.nk > 0) setup_item();
+    if (!has_bias) {                     // the epilogue adds the ring's row unconditionally
+        for (int i = tid; i < D * BN / 2; i += PG_THREADS) pg_lds_store8(pg_lds_addr(smem) + BIAS_BASE + i * 8, 0u, 0u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 
     int issued = 0;                      // stages issued so far (ring slot = issued % D)
     auto issue_next = [&]() {
@@ -301,7 +344,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             ls = 0;
             ++l_item;
             lw += grid;
-            if (lw < q.total) { lwk = pg_work<BM, BN, SRC>(q, lw); if (lwk.nk > 0) setup_item(); }
+            if (lw < q.total) { lwk = pg_next<BM, BN, SRC>(q, lwk, lw); if (lwk.nk > 0) setup_item(); }
             else lwk.nk = 0;
         }
     };
@@ -316,17 +359,17 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
 
     pg_f32x16 acc[FN][FM];
     int consumed = 0, c_item = 0;        // stages consumed / items finished by the compute side
-    float st1[NCH], st2[NCH];            // stats_acc: this thread's (channel tid % EN, row set tid / EN) sums over all tiles of the workgroup
+    pg_f32x2 st1[NCH], st2[NCH];         // stats_acc: this thread's (channel pair tid % (EN/2), row set tid / (EN/2)) sums over all tiles of the workgroup
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) st1[ch] = st2[ch] = 0.f;
+    for (int ch = 0; ch < NCH; ++ch) { st1[ch] = pg_f32x2{0.f, 0.f}; st2[ch] = pg_f32x2{0.f, 0.f}; }
     int st_n0 = 0;
 
 #pragma unroll 1
     for (int i = 0; i < D - 1; ++i) issue_next();
 
+    PGWork wk = pg_work<BM, BN, SRC>(q, blockIdx.x < q.total ? blockIdx.x : 0);
 #pragma unroll 1
-    for (int cw = blockIdx.x; cw < q.total; cw += grid) {
-        const PGWork wk = pg_work<BM, BN, SRC>(q, cw);
+    for (int cw = blockIdx.x; cw < q.total; cw += grid, wk = pg_next<BM, BN, SRC>(q, wk, cw < q.total ? cw : 0)) {
         if (wk.nk == 0) continue;        // (cannot happen with the host's split arithmetic; the load cursor skips such items the same way)
         const int m0 = wk.tile_m * BM, n0 = wk.tile_n * BN;
 #pragma unroll
@@ -338,7 +381,11 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
 #pragma unroll 1
         for (int s = 0; s < wk.nk; ++s) {
             // stage `consumed` must have landed: everything this wave issued for it is older than the newest (D-2) stages
+#ifdef PG_EXP_LAXWAIT       // experiment only (not safe in general): leave room for two epilogues' stores
+            if (issued - consumed - 1 >= D - 2) pg_wait_vmcnt<(D - 2) * L + 4>(); else pg_wait_vmcnt<0>();
+#else
             if (issued - consumed - 1 >= D - 2) pg_wait_vmcnt<(D - 2) * L>(); else pg_wait_vmcnt<0>();
+#endif
             __builtin_amdgcn_s_barrier();          // every wave's share has landed, and every wave is done with stage consumed-1
             issue_next();                          // refill the slot of stage consumed-1
             const unsigned char* slot = smem + (consumed % D) * SLOT_BYTES;
@@ -384,28 +431,35 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {                                 // 64 output channels at a time through the staging tile
             __builtin_amdgcn_s_barrier();                                  // every wave is done reading the slot / the previous chunk
+            // accumulators (+ bias: the ring holds zeros when there is none) -> activation -> 16-bit -> staging tile.  The activation and the
+            // ragged-Cout mask are resolved ONCE per tile (uniform), not per value.
+            auto stage_values = [&](auto ELU, auto RAGGED) {
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if ((wn * WTN + j * 32) / EN != ch) continue;              // wave-uniform
+                for (int j = 0; j < FN; ++j) {
+                    if ((wn * WTN + j * 32) / EN != ch) continue;              // wave-uniform
 #pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int row = wm * WTM + i * 32 + l31;
+                    for (int i = 0; i < FM; ++i) {
+                        const int row = wm * WTM + i * 32 + l31;
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int nt = wn * WTN + j * 32 + 8 * gq + 4 * lh;    // channel inside the tile
-                        float v[4];
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int nt = wn * WTN + j * 32 + 8 * gq + 4 * lh;    // channel inside the tile
+                            const pg_f32x4 b4 = *reinterpret_cast<const pg_f32x4*>(sbias + nt);
+                            float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t = acc[j][i][4 * gq + e];
-                            if (has_bias) t += sbias[nt + e];
-                            if (p.act == SDE_ACT_ELU) t = t > 0.f ? t : expm1f(t);
-                            if (n0 + nt + e >= p.Cout) t = 0.f;       // padded output channels are exact zeros
-                            v[e] = t;
+                            for (int e = 0; e < 4; ++e) {
+                                float t = acc[j][i][4 * gq + e] + b4[e];
+                                if (decltype(ELU)::value) t = t > 0.f ? t : expm1f(t);
+                                if (decltype(RAGGED)::value) { if (n0 + nt + e >= p.Cout) t = 0.f; }       // padded output channels are exact zeros
+                                v[e] = t;
+                            }
+                            pg_lds_store8(sC_a + row * CST + (nt - ch * EN) * 2, PgType<T16>::pack2(v[0], v[1]), PgType<T16>::pack2(v[2], v[3]));
                         }
-                        pg_lds_store8(sC_a + row * CST + (nt - ch * EN) * 2, PgType<T16>::pack2(v[0], v[1]), PgType<T16>::pack2(v[2], v[3]));
                     }
                 }
-            }
+            };
+            const bool ragged = n0 + BN > p.Cout;
+            if (p.act == SDE_ACT_ELU) { if (ragged) stage_values(PgIC<1>{}, PgIC<1>{}); else stage_values(PgIC<1>{}, PgIC<0>{}); }
+            else { if (ragged) stage_values(PgIC<0>{}, PgIC<1>{}); else stage_values(PgIC<0>{}, PgIC<0>{}); }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             // NOTE: LDS is read through ext_vector types only.  A load typed as a HIP struct vector (uint4, float4 ...) carries struct TBAA info,
@@ -439,23 +493,30 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             for (int id = tid; id < BM * G8; id += PG_THREADS) {
                 const int row = id / G8, c8 = id - row * G8;
                 const int m = m0 + row, n = nc0 + c8 * 8;
+#ifdef PG_EXP_NOSTORE
+                if (m < 0)
+#else
                 if (m < g.M && n < p.ldy)                                   // ldy % 8 == 0
+#endif
                     *reinterpret_cast<u32x4*>((unsigned char*)p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const u32x4*>(sC + row * CST + c8 * 16);
             }
             }
             if (p.stats) {
                 // per-tile column sums of y and y^2 (of the rounded values) over the valid rows: PARTS interleaved row sets per column
-                constexpr int PARTS = PG_THREADS / EN;
+                // thread = (channel pair tid % (EN/2), row set tid / (EN/2)): one 4-byte LDS read per row, packed fp32 math
+                constexpr int PARTS = PG_THREADS / (EN / 2);
                 float* red = reinterpret_cast<float*>(sC + BM * CST);       // [PARTS][EN][2]
-                const int c = tid % EN, part = tid / EN;
+                const int c2 = tid % (EN / 2), part = tid / (EN / 2);
                 const int rows = (g.M - m0) < BM ? (g.M - m0) : BM;
-                float s1 = 0.f, s2 = 0.f;
+                pg_f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll 4
                 for (int r = part; r < rows; r += PARTS) {
-                    const float t = (float)*reinterpret_cast<const T16*>(sC + r * CST + c * 2);
+                    const pg_f32x2 t = PgType<T16>::unpack2(*reinterpret_cast<const unsigned*>(sC + r * CST + c2 * 4));
                     s1 += t; s2 += t * t;
                 }
                 if (q.stats_acc) { st1[ch] += s1; st2[ch] += s2; st_n0 = n0; continue; }
-                pg_lds_store8(sC_a + BM * CST + (part * EN + c) * 8, __builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s2));
+                // (one 16-byte store: two 8-byte asm stores fed from the halves of the packed sums were given the SAME register pair by hipcc)
+                pg_lds_store16(sC_a + BM * CST + (part * EN + 2 * c2) * 8, s1[0], s2[0], s1[1], s2[1]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (tid < EN && nc0 + tid < p.Cout) {
@@ -472,12 +533,14 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     }
     pg_wait_vmcnt<0>();      // nothing may be in flight into LDS when the workgroup ends
     if (p.stats && q.stats_acc) {
-        constexpr int PARTS = PG_THREADS / EN;
+        constexpr int PARTS = PG_THREADS / (EN / 2);
         float* red = reinterpret_cast<float*>(smem);                       // [NCH][PARTS][EN][2]
         __builtin_amdgcn_s_barrier();                                      // every wave is done with the ring
+        const int c2 = tid % (EN / 2), part = tid / (EN / 2);
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-            pg_lds_store8(pg_lds_addr(smem) + (ch * PG_THREADS + tid) * 8, __builtin_bit_cast(unsigned, st1[ch]), __builtin_bit_cast(unsigned, st2[ch]));
+        for (int ch = 0; ch < NCH; ++ch) {
+            pg_lds_store16(pg_lds_addr(smem) + (((ch * PARTS + part) * EN) + 2 * c2) * 8, st1[ch][0], st2[ch][0], st1[ch][1], st2[ch][1]);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const int row = (blockIdx.x & 7) * ((grid >> 3) / q.tiles_n) + (blockIdx.x >> 3) / q.tiles_n;
@@ -518,7 +581,10 @@ static int pg_launch(const PGemmP& q, hipStream_t s) {
     }
     int grid = pg_grid_max(BM, BN, D);
     if (grid > q.total) grid = q.total;
-    hipLaunchKernelGGL((pgemm_kernel<T16, BM, BN, SRC, D>), dim3(grid), dim3(PG_THREADS), lds, s, q);
+    PGemmP qq = q;
+    qq.fast = (q.p.ksplit == 1 && SRC != SRC_ZEROINS_ZERO && grid % 8 == 0 && (grid >> 3) % q.tiles_n == 0) ? 1 : 0;
+    qq.tm_step = qq.fast ? (grid >> 3) / q.tiles_n : 0;
+    hipLaunchKernelGGL((pgemm_kernel<T16, BM, BN, SRC, D>), dim3(grid), dim3(PG_THREADS), lds, s, qq);
     return 0;
 }
 

@@ -134,7 +134,9 @@ def test_every_resnet50_layer_at_full_batch_unforced(layer_table):
             yy = y[..., :Cout].double().reshape(-1, Cout)
             ref = torch.stack([yy.sum(0), (yy * yy).sum(0)], 1).cpu()
             tot = stats[: stats.shape[0] - NN.REDUCE_ROWS].double().sum(0).cpu()
-            assert ((tot - ref).abs() <= 1e-3 * ref.abs() + 1e-2).all(), f"{name}: BatchNorm partial sums"
+            bad = ((tot - ref).abs() > 1e-3 * ref.abs() + 1e-2)
+            assert not bad.any(), (f"{name}: BatchNorm partial sums: {int(bad.sum())} of {bad.numel()} wrong, first at {bad.nonzero()[:4].tolist()}, "
+                                   f"got {tot[bad][:4].tolist()} want {ref[bad][:4].tolist()}; slab rows {stats.shape[0] - NN.REDUCE_ROWS}")
     print("\nlayer (per image)                              uses  variant   err(y)    err(dX)   err(dW)")
     for name, count, variant, e_y, e_dx, e_dw in rows:
         print(f"{name:46s} {count:4d}  {variant:8d}  {e_y:.2e}  {e_dx:.2e}  {e_dw:.2e}")
