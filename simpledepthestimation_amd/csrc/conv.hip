@@ -1131,6 +1131,42 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const sde_pack_item* 
     const int n_ci_real = max(0, min(CI, it.Cin - ci0));          // channels that exist in the master weights
     const int n_ci = min(CI, it.Cin_pad - ci0), n_co = min(PACK_CO, it.Cout_pad - co0);
     const int seg = n_ci_real * khw, rs = CI * khw + 1;           // row stride odd: the transposed reads below are conflict-free
+    // Fast path (16-bit operands of channels-last master weights without channel padding -- every layer but the stem and the 1-channel heads):
+    // float4 loads, LDS tile in source order [co][tap][ci], and 16-byte stores of 8 values -- 8 consecutive ci of the forward operand, 8
+    // consecutive co of the data-gradient operand -- instead of one index computation and one 2-byte store per element.
+    if constexpr (sizeof(T) == 2)
+    if ((it.src_layout == SDE_W_OHWI || khw == 1) && it.Cin_pad == it.Cin && it.Cout_pad == it.Cout && (it.Cin & 7) == 0 && (it.Cout & 7) == 0 && it.dst_fwd && it.dst_dgrad) {
+        const int nq = n_ci >> 2;                                  // float4 per (co, tap) run
+        for (int idx = threadIdx.x; idx < n_co * khw * nq; idx += 256) {
+            const int q4 = idx % nq, t2 = idx / nq, tap = t2 % khw, co_l = t2 / khw;
+            const float4 v = *reinterpret_cast<const float4*>(it.src + ((size_t)(co0 + co_l) * khw + tap) * it.Cin + ci0 + q4 * 4);
+            float* d = tile + co_l * rs + tap * n_ci + q4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+        const int n8 = n_ci >> 3;
+        T* dstf = (T*)it.dst_fwd;
+        for (int idx = threadIdx.x; idx < n_co * khw * n8; idx += 256) {
+            const int c8 = idx % n8, t2 = idx / n8, tap = t2 % khw, co_l = t2 / khw;
+            const float* sp = tile + co_l * rs + tap * n_ci + c8 * 8;
+            us8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_bit_cast(unsigned short, from_f32<T>(sp[j]));
+            *reinterpret_cast<us8*>(dstf + ((size_t)(co0 + co_l) * khw + tap) * it.Cin_pad + ci0 + c8 * 8) = o;
+        }
+        const int m8 = n_co >> 3;
+        T* dstd = (T*)it.dst_dgrad;
+        for (int idx = threadIdx.x; idx < n_ci * khw * m8; idx += 256) {
+            const int o8 = idx % m8, t2 = idx / m8, tapf = t2 % khw, ci_l = t2 / khw;
+            const float* sp = tile + (o8 * 8) * rs + (khw - 1 - tapf) * n_ci + ci_l;
+            us8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_bit_cast(unsigned short, from_f32<T>(sp[j * rs]));
+            *reinterpret_cast<us8*>(dstd + ((size_t)(ci0 + ci_l) * khw + tapf) * it.Cout_pad + co0 + o8 * 8) = o;
+        }
+        return;
+    }
     if (seg > 0 && it.src_layout == SDE_W_OHWI) {      // channels-last master weights [co][tap][ci]: contiguous along ci
         for (int idx = threadIdx.x; idx < PACK_CO * seg; idx += 256) {
             const int ci_l = idx % n_ci_real, t2 = idx / n_ci_real, tap = t2 % khw, co_l = t2 / khw;

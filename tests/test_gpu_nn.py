@@ -361,14 +361,20 @@ def test_conv3d_pack(NN, dtype, B, D, H, W):
     check(bd.grad.cpu(), br.grad, dtype, "conv3d dbias", 2e-5, 2e-5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_weight_packer_equals_per_layer_pack(NN, dtype):
-    """sde_pack_weights_batched (LDS-tiled, every layer in one launch) == sde_pack_weight per layer and operand, bit for bit."""
+@pytest.mark.parametrize("layout", ["oihw", "ohwi"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_weight_packer_equals_per_layer_pack(NN, dtype, layout):
+    """sde_pack_weights_batched (LDS-tiled, every layer in one launch) == sde_pack_weight per layer and operand, bit for bit.
+    "ohwi": channels-last master weights, as HipTrainer keeps them (16-bit operands without channel padding take the vectorised path)."""
     from simpledepthestimation_amd.layers.hip_modules import HipConv2d
     V = 4 if dtype == torch.float32 else 8
     shapes = [(3, 64, 7), (64, 64, 3), (193, 128, 3), (256, 64, 5), (64, 256, 1), (16, 1, 3), (520, 40, 3), (2048, 24, 1)]
     torch.manual_seed(5)
     net = torch.nn.ModuleList([HipConv2d(ci, co, k, padding=k // 2) for ci, co, k in shapes]).to(dev)
+    if layout == "ohwi":
+        for m in net:
+            m.weight.data = m.weight.data.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            assert NN.is_ohwi(m.weight) or m.kernel_size == 1          # (a 1x1 weight is the same memory either way)
     for m, (ci, co, k) in zip(net, shapes):
         x = torch.zeros(1, 8, 8, (ci + V - 1) // V * V, device=dev, dtype=dtype)
         m(x)                                   # records the padded operand shapes
