@@ -180,6 +180,8 @@ int sde_conv_set_halo_min_blocks(int min_blocks);
 #define SDE_OPT_WGRAD_BLOCKS 6 /* workgroup target of the weight-gradient GEMM's pixel splits (default 256 = one per CU) */
 #define SDE_OPT_WGRAD_HALO 7   /* 1 (default): the 3x3 stride-1 layers with <= 96 input and <= 32 output channels take the LDS-halo weight-gradient
                                   kernel (csrc/wgrad_halo.hip); 0: the generic kernel */
+#define SDE_OPT_CONV_SMALL 8   /* 1 (default): 3x3 stride-1 layers with 8 / 16 / 32 input channels and >= 16 K output pixels take the narrow-input halo
+                                  kernel (csrc/conv_halo_small.hip) in the forward and data-gradient passes; 0: the generic kernel */
 int sde_conv_set_option(int key, int value);
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).

@@ -1385,6 +1385,9 @@ bool pgemm_applicable(const Gather& g, int dtype, int ldy);
 int pgemm_tile(long M, int ldy);
 int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s);
 int pgemm_stats_rows(const Gather& g, int ldy, int depth);
+// narrow-input 3x3 layers at high resolution (conv_halo_small.hip)
+bool chalo_applicable(const Gather& g, int dtype, int ldy);
+int chalo_run(const IGemmP& p, int dtype, hipStream_t s);
 // halo weight gradient of the small-channel 3x3 layers (wgrad_halo.hip)
 bool whalo_applicable(const Gather& g, int dtype, int Cout, int ldd);
 int whalo_splits(const Gather& g, int Cout);
@@ -1426,6 +1429,9 @@ static int pick_ksplit(const Gather& g, int dtype, int ldy) {
     return S < 2 ? 1 : (int)S;
 }
 
+int g_conv_small = 1;       // SDE_OPT_CONV_SMALL
+static bool use_chalo(const Gather& g, int dtype, int ldy) { return g_conv_small && sdeconv::chalo_applicable(g, dtype, ldy); }
+
 static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats,
                          float* ws, size_t ws_bytes, sde_stream_t stream) {
     SDE_CHECK_ARG(d && w_packed && y, "sde_conv_fwd: null pointer");
@@ -1442,7 +1448,9 @@ static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const flo
         SDE_CHECK_ARG(ws_bytes >= (size_t)S * p.g.M * ldy * sizeof(float), "sde_conv_fwd_ws: workspace too small (%zu bytes)", ws_bytes);
         p.ksplit = S; p.ws = ws;
     }
-    if (use_pgemm(p.g, d->dtype, ldy)) {
+    if (!stats && p.ksplit == 1 && use_chalo(p.g, d->dtype, ldy)) {
+        sdeconv::chalo_run(p, d->dtype, (hipStream_t)stream);
+    } else if (use_pgemm(p.g, d->dtype, ldy)) {
         SDE_CHECK_ARG((p.ksplit - 1) * sde_cdiv(p.g.Ktot / 64, p.ksplit) < p.g.Ktot / 64, "sde_conv_fwd: empty K split");
         // sde_conv_fwd_tiles_m does not know whether a workspace will be passed: a split layer's statistics slab has one row per 64 rows
         SDE_CHECK_ARG(p.ksplit == 1 || sdeconv::pgemm_stats_rows(p.g, ldy, g_pgemm_depth) == sde_cdiv(p.g.M, 64), "sde_conv_fwd: split-K layer with per-workgroup statistics");
@@ -1484,6 +1492,7 @@ static int gather_of(const sde_conv_desc* d, Gather& g) { return fill_gather(d, 
 
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
     Gather g;
+    if (gather_of(d, g) == SDE_OK && use_chalo(g, d->dtype, ldy)) return 5000000 + g.Cin * 1000 + ldy;            // 5<Cin><ldy>: narrow-input halo kernel (without BN statistics)
     if (gather_of(d, g) == SDE_OK && use_pgemm(g, d->dtype, ldy)) return 7000000 + pgemm_tile(g.M, ldy);   // 7<BM><BN>: persistent LDS-DMA GEMM
     if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return 3128000 + halo_bn(g, ldy);      // 3128<BN>: LDS-halo 3x3 kernel
     return pick_tile((long)d->Bn * d->OH * d->OW, ldy, d->KH * d->KW * (d->C0 + d->C1));
@@ -1658,7 +1667,7 @@ int sde_conv_set_option(int key, int value) {
         return old;
     }
     int* slot = key == SDE_OPT_PGEMM ? &g_use_pgemm : key == SDE_OPT_PGEMM_DEPTH ? &g_pgemm_depth : key == SDE_OPT_PGEMM_3X3 ? &g_pgemm_3x3 :
-                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : nullptr;
+                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : key == SDE_OPT_CONV_SMALL ? &g_conv_small : nullptr;
     SDE_CHECK_ARG(slot, "sde_conv_set_option: unknown key %d", key);
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_DEPTH || value == 3 || value == 4, "sde_conv_set_option: ring depth must be 3 or 4");
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_TILE || value == 0 || value == 64064 || value == 128064 || value == 128128, "sde_conv_set_option: bad tile %d", value);
