@@ -32,10 +32,24 @@ void sde_set_error(const char* fmt, ...);
 static inline int sde_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers -------------------------------------------------------------------------
+// Sum over the 64 lanes of a wave, returned in every lane.  DPP adds instead of six __shfl_xor steps (ds_bpermute_b32: an LDS-crossbar round
+// trip each): quad swaps, row half-mirror and mirror give every lane its 16-lane row sum; row_bcast15 / row_bcast31 chain the four rows into
+// lane 63, which v_readlane broadcasts.  Fixed order: deterministic.
 __device__ __forceinline__ float sde_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    auto step = [](float x, auto CTRL, auto ROWS) {
+        const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(CTRL)::value, decltype(ROWS)::value, 0xf, false);
+        return x + __builtin_bit_cast(float, moved);
+    };
+    struct C_B1 { enum { value = 0xB1 }; }; struct C_4E { enum { value = 0x4E }; }; struct C_141 { enum { value = 0x141 }; };
+    struct C_140 { enum { value = 0x140 }; }; struct C_142 { enum { value = 0x142 }; }; struct C_143 { enum { value = 0x143 }; };
+    struct R_F { enum { value = 0xf }; }; struct R_A { enum { value = 0xa }; }; struct R_C { enum { value = 0xc }; };
+    v = step(v, C_B1{}, R_F{});      // quad_perm [1,0,3,2]
+    v = step(v, C_4E{}, R_F{});      // quad_perm [2,3,0,1]
+    v = step(v, C_141{}, R_F{});     // row_half_mirror
+    v = step(v, C_140{}, R_F{});     // row_mirror: every lane holds its row's sum
+    v = step(v, C_142{}, R_A{});     // row_bcast15 into rows 1 and 3
+    v = step(v, C_143{}, R_C{});     // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Sum over a block (blockDim multiple of 64, <= 1024). Result valid in thread 0. `red` >= 16 floats.
