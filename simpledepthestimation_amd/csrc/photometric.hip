@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(BT_N) photo_bwd_kernel(PhotoBwdArgs a) {
     float* sA = lds;                  // [3][BT_N]
     float* sX = sA + 3 * BT_N;        // [3][BT_N]     current context's warped sample
     float* sK = sX + 3 * BT_N;        // [3][3][BT_N]  per-window coefficients (dA, dB, dC) per channel
-    float* red = sK + 9 * BT_N;       // [16 * 12]
+    float* red = sK + 9 * BT_N;       // [waves][NCTX][12]
     const int tx = threadIdx.x, ty = threadIdx.y, lp = ty * BT_W + tx;
     const int b = blockIdx.z, h = a.h, w = a.w;
     const long hw = (long)h * w;
@@ -484,19 +484,18 @@ __global__ void __launch_bounds__(BT_N) photo_bwd_kernel(PhotoBwdArgs a) {
                 acc12[9 + m] = kq;
             }
         }
-        // block reduction of the 12 pose-gradient terms
+        // the 12 pose-gradient terms: wave sums now (every wave owns its slots of `red`: no barrier), the block sum once after the loop
 #pragma unroll
         for (int i = 0; i < 12; ++i) acc12[i] = sde_wave_sum(acc12[i]);
-        __syncthreads();
         if ((lp & 63) == 0)
 #pragma unroll
-            for (int i = 0; i < 12; ++i) red[(lp >> 6) * 12 + i] = acc12[i];
-        __syncthreads();
-        if (lp < 12) {
-            float s = 0.f;
-            for (int wv = 0; wv < BT_N / 64; ++wv) s += red[wv * 12 + lp];
-            a.pose_partial[((long)blk * NCTX + j) * 12 + lp] = s;
-        }
+            for (int i = 0; i < 12; ++i) red[((lp >> 6) * NCTX + j) * 12 + i] = acc12[i];
+    }
+    __syncthreads();
+    if (lp < 12 * NCTX) {
+        float s = 0.f;
+        for (int wv = 0; wv < BT_N / 64; ++wv) s += red[wv * NCTX * 12 + lp];
+        a.pose_partial[(long)blk * NCTX * 12 + lp] = s;
     }
     if (interior) {
         float* o = a.d_depth + b * hw + pix;
@@ -809,7 +808,7 @@ int sde_resize(const float* src, float* dst, int planes, int H, int W, int h, in
 }
 
 static size_t photo_fwd_lds(int nctx) { return (size_t)((3 + 6 * nctx) * FT_N + 16) * sizeof(float); }
-static size_t photo_bwd_lds() { return (size_t)((3 + 3 + 9) * BT_N + 16 * 12) * sizeof(float); }
+static size_t photo_bwd_lds() { return (size_t)((3 + 3 + 9) * BT_N + (BT_N / 64) * SDE_MAX_CTX * 12) * sizeof(float); }
 
 int sde_photo_num_blocks(int B, int h, int w, int backward) {
     if (backward) return sde_cdiv(w, BT_W - 4) * sde_cdiv(h, BT_H - 4) * B;
