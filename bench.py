@@ -75,22 +75,22 @@ def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50"):
             trainer._backward_rest()
     one()                                        # eager warm-up (the timed region may have run under graph replay)
     torch.cuda.synchronize()
-    L.PROFILE = []
+    L.PROFILE, L.PROFILE_REPEAT = [], 6          # each GEMM launch six times back to back between its two events (lib.timed)
     for _ in range(steps):
         one()
     torch.cuda.synchronize()
-    recs, L.PROFILE = L.PROFILE, None
+    recs, L.PROFILE, L.PROFILE_REPEAT = L.PROFILE, None, 1
     fam = {}
     if os.environ.get("SDE_BENCH_LAYER_DUMP"):
         with open(os.environ["SDE_BENCH_LAYER_DUMP"], "w") as f:
             f.write("kind,variant,M,N,K,k,stride,mode,splits,us,tflops,unique_GBps\n")
-            for kind, flops, variant, e0, e1, meta in recs[:len(recs) // steps]:
-                us = e0.elapsed_time(e1) * 1e3
+            for kind, flops, variant, e0, e1, meta, rep in recs[:len(recs) // steps]:
+                us = e0.elapsed_time(e1) * 1e3 / rep
                 m = meta or {}
                 f.write(f"{kind},{variant},{m.get('M')},{m.get('N')},{m.get('K')},{m.get('k')},{m.get('s')},{m.get('mode')},{m.get('splits', '')},"
                         f"{us:.1f},{flops / us / 1e6:.1f},{m.get('bytes', 0) / us / 1e3:.0f}\n")
     photo = {}
-    for kind, nbytes, variant, e0, e1, meta in recs:
+    for kind, nbytes, variant, e0, e1, meta, _rep in recs:
         if kind.startswith("photo"):
             f = photo.setdefault((kind, meta["h"], meta["w"]), {"ms": 0.0, "bytes": 0.0, "launches": 0})
             f["ms"] += e0.elapsed_time(e1); f["bytes"] += nbytes; f["launches"] += 1
@@ -105,10 +105,10 @@ def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50"):
                "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                "all": {f"{k[0]}:{k[1]}x{k[2]}": {"us": round(x["ms"] * 1e3 / x["launches"], 2), "GBps": round(x["bytes"] / (x["ms"] * 1e-3) / 1e9, 1)}
                        for k, x in sorted(photo.items(), key=lambda kv: -kv[0][1])}}
-    for kind, flops, variant, e0, e1, _meta in recs:
+    for kind, flops, variant, e0, e1, _meta, rep in recs:
         key = ("igemm" if kind.startswith("igemm") else kind, variant)
         f = fam.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
-        f["ms"] += e0.elapsed_time(e1); f["flops"] += flops; f["launches"] += 1
+        f["ms"] += e0.elapsed_time(e1) / rep; f["flops"] += flops; f["launches"] += 1
     dom_key = max(fam, key=lambda k: fam[k]["ms"])
     dom = fam[dom_key]
     peak = MFMA_PEAK_TFLOPS[dtype]

@@ -58,15 +58,15 @@ for name, B, H, W, Cin, Cout, k, s, p, refl, C1 in SHAPES:
     gy = torch.randn_like(y)
     res = {}
     for _ in range(3):
-        L.PROFILE = []
+        L.PROFILE, L.PROFILE_REPEAT = [], 6        # six launches per event pair (lib.timed): the pair itself costs ~10 us
         for _ in range(5):
             y = fwd()
             y.backward(gy)
             w.grad = None
         torch.cuda.synchronize()
         recs, L.PROFILE = L.PROFILE, None
-        for kind, flops, variant, e0, e1, meta in recs:
-            res.setdefault(kind, []).append((e0.elapsed_time(e1) * 1e3, flops))
+        for kind, flops, variant, e0, e1, meta, rep in recs:
+            res.setdefault(kind, []).append((e0.elapsed_time(e1) * 1e3 / rep, flops))
     def stat(kind):
         if kind not in res: return (0.0, 0.0)
         us = sorted(r[0] for r in res[kind])[len(res[kind]) // 2]
