@@ -143,7 +143,7 @@ def pmc_traffic(dom_key, dtype):
     kind, variant = dom_key
     if kind == "igemm":
         if variant >= 7000000:
-            pat = f"pgemm_kernelILi{(variant - 7000000) // 1000}ELi{variant % 1000}E"
+            pat = f"pgemm_kernelIDF16{'b' if dtype == 'bf16' else '_'}Li{(variant - 7000000) // 1000}ELi{variant % 1000}E"
         else:
             pat = "halo3_kernel" if variant >= 3000000 else f"igemm_kernelIDF16bLi{variant // 1000}ELi{variant % 1000}E"
     elif kind == "wgrad":
