@@ -225,6 +225,8 @@ int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu
 /* BatchNorm(+ReLU, +residual) backward.  The normalised output may have up to three consumers whose gradients arrive separately
  * (dout, dout1, dout2; the latter two may be NULL): they are summed on the fly.  gm [M,C] (workspace, required when relu is set or more than
  * one gradient is given) receives dz = relu'(out) * (sum of the gradients) -- which is also the gradient of the residual input.
+ * out: the saved forward output (ReLU mask).  With relu set and out == NULL the mask is re-derived from y and bnp as fma(y, scale, shift) > 0 --
+ * valid only when the forward had NO residual (then it equals out > 0, and one activation-sized stream less is read).
  * part: [sde_reduce_num_blocks(M, C) + SDE_REDUCE_ROWS][C][2] workspace, coef: [2][C] workspace.  dy [M,C]; dgamma/dbeta [C] (+)=. */
 int sde_reduce_num_blocks(long M, int C);
 int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const void* out, const void* y, const float* bnp, const float* gamma, int relu,

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, 
         if (res) load_vec<T>(res + i * V, r);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            float t = v[e] * bnp[2 * C + c0 + e] + bnp[3 * C + c0 + e];
+            float t = fmaf(v[e], bnp[2 * C + c0 + e], bnp[3 * C + c0 + e]);      // (bn_bwd_reduce re-derives the ReLU mask from exactly this expression)
             if (res) t += r[e];
             if (relu) t = fmaxf(t, 0.f);
             v[e] = t;
@@ -236,8 +236,11 @@ __device__ __forceinline__ void round_vec(float* d) {       // values as they co
     for (int e = 0; e < V; ++e) d[e] = (float)(T)d[e];
 }
 
+// relu: 0 none; 1 mask from the saved output; 2 mask re-derived from y (BatchNorm + ReLU WITHOUT a residual: out > 0 <=> fma(y, scale, shift) > 0,
+// the expression bn_apply_kernel evaluates) -- one activation-sized stream less to read (two of three BatchNorms of a bottleneck block)
 template <typename T, int V>
-__device__ __forceinline__ void bn_load_dz(const T* d0, const T* d1, const T* d2, const T* out, int relu, long off, float* d) {
+__device__ __forceinline__ void bn_load_dz(const T* d0, const T* d1, const T* d2, const T* out, int relu, long off, float* d, const float* yv,
+                                           const float* sc, const float* sf) {
     load_vec<T>(d0 + off, d);
     if (d1) {
         float t[V];
@@ -251,11 +254,14 @@ __device__ __forceinline__ void bn_load_dz(const T* d0, const T* d1, const T* d2
 #pragma unroll
         for (int e = 0; e < V; ++e) d[e] += t[e];
     }
-    if (relu) {
+    if (relu == 1) {
         float o[V];
         load_vec<T>(out + off, o);
 #pragma unroll
         for (int e = 0; e < V; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+    } else if (relu == 2) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] = fmaf(yv[e], sc[e], sf[e]) > 0.f ? d[e] : 0.f;
     }
 }
 
@@ -269,14 +275,17 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
     const int cch = C / V;
     if (cch <= 256 && 256 % cch == 0) {
         const int col = threadIdx.x % cch, c0 = col * V;
-        float mean[V], rstd[V], acc[2 * V];
+        float mean[V], rstd[V], sc[V], sf[V], acc[2 * V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) { mean[e] = bnp[c0 + e]; rstd[e] = bnp[C + c0 + e]; acc[e] = 0.f; acc[V + e] = 0.f; }
+        for (int e = 0; e < V; ++e) {
+            mean[e] = bnp[c0 + e]; rstd[e] = bnp[C + c0 + e]; sc[e] = bnp[2 * C + c0 + e]; sf[e] = bnp[3 * C + c0 + e];
+            acc[e] = 0.f; acc[V + e] = 0.f;
+        }
         const long total = M * cch;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
             float d[V], yv[V];
-            bn_load_dz<T, V>(dout, dout1, dout2, out, relu, i * V, d);
             load_vec<T>(y + i * V, yv);
+            bn_load_dz<T, V>(dout, dout1, dout2, out, relu, i * V, d, yv, sc, sf);
             if (gm) {
                 round_vec<T, V>(d);              // the sums must see what the apply pass will read back
                 store_vec<T>(gm + i * V, d);
@@ -303,8 +312,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
         const int col = (int)(i % cch), c0 = col * V;
         const long off = (r0 * cch + i) * V;
         float d[V], yv[V];
-        bn_load_dz<T, V>(dout, dout1, dout2, out, relu, off, d);
         load_vec<T>(y + off, yv);
+        bn_load_dz<T, V>(dout, dout1, dout2, out, relu, off, d, yv, bnp + 2 * C + c0, bnp + 3 * C + c0);
         if (gm) {
             round_vec<T, V>(d);
             store_vec<T>(gm + off, d);
@@ -1063,7 +1072,7 @@ int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const voi
                sde_stream_t stream) {
     const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(dout && y && bnp && part && coef && dgamma && dbeta && dy && M > 0 && C > 0 && C % V == 0, "sde_bn_bwd: bad argument");
-    SDE_CHECK_ARG(!relu || out, "sde_bn_bwd: relu needs the saved output");
+    if (relu && !out) relu = 2;          // BatchNorm + ReLU without a residual: the mask is re-derived from y and the BN parameters
     SDE_CHECK_ARG(gm || (!relu && !dout1 && !dout2), "sde_bn_bwd: a masked or summed gradient needs the gm buffer");
     SDE_CHECK_ARG(dout1 || !dout2, "sde_bn_bwd: dout2 without dout1");
     (void)gamma;

@@ -552,7 +552,9 @@ class _BatchNormAct(torch.autograd.Function):
                     "sde_bn_eval_params")
         out = torch.empty_like(y)
         L.check(lib.sde_bn_apply(L.ptr(y), L.ptr(bnp), L.ptr(residual), int(relu), M, C, dtype_code(dt), L.ptr(out), L.stream()), "sde_bn_apply")
-        ctx.save_for_backward(y, out if relu else None, bnp, gamma)
+        # backward needs the ReLU mask: with a residual it comes from the saved output; without one sde_bn_bwd re-derives it from y and the
+        # BatchNorm parameters (out = NULL), so that tensor is neither kept for backward nor read by it
+        ctx.save_for_backward(y, out if (relu and residual is not None) else None, bnp, gamma)
         ctx.params = (gamma, beta)
         ctx.cfg = (relu, residual is not None, training)
         if n_out == 1:
