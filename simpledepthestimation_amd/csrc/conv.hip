@@ -1388,6 +1388,9 @@ int pgemm_stats_rows(const Gather& g, int ldy, int depth);
 // narrow-input 3x3 layers at high resolution (conv_halo_small.hip)
 bool chalo_applicable(const Gather& g, int dtype, int ldy);
 int chalo_run(const IGemmP& p, int dtype, hipStream_t s);
+// weight gradient on LDS-DMA for 64-channel-multiple layers (wgrad_dma.hip)
+bool wgrad_dma_applicable(const Gather& g, int dtype, int Cout, int ldd);
+int wgrad_dma_run(const Gather& g, int dtype, const void* dy, int Cout, int ldd, float* slab, int splits, int rows_per_split, hipStream_t s);
 // halo weight gradient of the small-channel 3x3 layers (wgrad_halo.hip)
 bool whalo_applicable(const Gather& g, int dtype, int Cout, int ldd);
 int whalo_splits(const Gather& g, int Cout);
@@ -1508,6 +1511,7 @@ int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy) {
 }
 
 int g_wgrad_halo = 1;       // SDE_OPT_WGRAD_HALO
+int g_wgrad_dma = 1;        // SDE_OPT_WGRAD_DMA
 static bool use_whalo(const Gather& g, int dtype, int Cout, int ldd) { return g_wgrad_halo && sdeconv::whalo_applicable(g, dtype, Cout, ldd); }
 
 int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
@@ -1549,6 +1553,15 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     int rps = sde_cdiv(p.g.M, splits);
     rps = sde_cdiv(rps, BR) * BR;
     SDE_CHECK_ARG((long)rps * splits >= p.g.M, "sde_conv_wgrad: split arithmetic");
+    // 1x1 stride-1 layers: 11-16 us against 14-21 us for the register-staged kernel; its 3x3 / strided form measured SLOWER (35-40 vs 27-30 us,
+    // profiles/README.md item 16) and stays behind option value 2
+    const bool wd_one = p.g.KH == 1 && p.g.stride == 1 && p.g.pad == 0;
+    if (g_wgrad_dma && (wd_one || g_wgrad_dma == 2) && sdeconv::wgrad_dma_applicable(p.g, d->dtype, Cout, ldd)) {
+        sdeconv::wgrad_dma_run(p.g, d->dtype, dy, Cout, ldd, slab, splits, rps, s);
+        SDE_CHECK_LAUNCH("sde_conv_wgrad (LDS-DMA)");
+        g = p.g;
+        return SDE_OK;
+    }
     p.dy = dy; p.slab = slab; p.Cout = Cout; p.ldd = ldd; p.rows_per_split = rps;
     p.single_buf = SDE_IS16(d->dtype) ? 1 : 0;      // one LDS stage buffer for the 16-bit tiles: 3 workgroups per CU, measured -0.7 % step time
     if (d->dtype == SDE_BF16) dispatch_wgrad<bf16_t>(p, splits, s);
@@ -1667,7 +1680,7 @@ int sde_conv_set_option(int key, int value) {
         return old;
     }
     int* slot = key == SDE_OPT_PGEMM ? &g_use_pgemm : key == SDE_OPT_PGEMM_DEPTH ? &g_pgemm_depth : key == SDE_OPT_PGEMM_3X3 ? &g_pgemm_3x3 :
-                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : key == SDE_OPT_CONV_SMALL ? &g_conv_small : nullptr;
+                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : key == SDE_OPT_CONV_SMALL ? &g_conv_small : key == SDE_OPT_WGRAD_DMA ? &g_wgrad_dma : nullptr;
     SDE_CHECK_ARG(slot, "sde_conv_set_option: unknown key %d", key);
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_DEPTH || value == 3 || value == 4, "sde_conv_set_option: ring depth must be 3 or 4");
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_TILE || value == 0 || value == 64064 || value == 128064 || value == 128128, "sde_conv_set_option: bad tile %d", value);
