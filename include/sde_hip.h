@@ -182,8 +182,8 @@ int sde_conv_set_halo_min_blocks(int min_blocks);
                                   kernel (csrc/wgrad_halo.hip); 0: the generic kernel */
 #define SDE_OPT_CONV_SMALL 8   /* 1 (default): 3x3 stride-1 layers with 8 / 16 / 32 input channels and >= 16 K output pixels take the narrow-input halo
                                   kernel (csrc/conv_halo_small.hip) in the forward and data-gradient passes; 0: the generic kernel */
-#define SDE_OPT_WGRAD_DMA 9    /* 1 (default): 1x1 stride-1 layers with 64-channel-multiple inputs and outputs take the LDS-DMA weight-gradient kernel
-                                  (csrc/wgrad_dma.hip); 2: also the k x k / strided ones (measured slower); 0: the register-staged kernel */
+#define SDE_OPT_WGRAD_DMA 9    /* 1 (default): layers with 64-channel-multiple inputs and outputs (zero padding, no concat) take the LDS-DMA weight-gradient
+                                  kernel (csrc/wgrad_dma.hip); 0: the register-staged kernel */
 int sde_conv_set_option(int key, int value);
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).

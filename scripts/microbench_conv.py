@@ -30,10 +30,10 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride, pad, reflect, upcat(C1)
     ("dec_up20_128_64", 12, 24, 80, 128, 64, 3, 1, 1, True, 0),
     ("dec_up10_64_32", 12, 48, 160, 64, 32, 3, 1, 1, True, 0),
 ]
-for key, env in ((HN.OPT_PGEMM, "PG"), (HN.OPT_PGEMM_DEPTH, "PGD"), (HN.OPT_PGEMM_3X3, "PG3"), (HN.OPT_WGRAD_DMA, "WD")):
+for key, env in ((HN.OPT_PGEMM, "PG"), (HN.OPT_PGEMM_DEPTH, "PGD"), (HN.OPT_PGEMM_3X3, "PG3"), (HN.OPT_WGRAD_DMA, "WD"), (HN.OPT_WGRAD_BLOCKS, "WB")):
     if os.environ.get(env) is not None:
         HN.set_option(key, int(os.environ[env]))
-print("options:", {e: os.environ.get(e) for e in ("PG", "PGD", "PG3", "WD")})
+print("options:", {e: os.environ.get(e) for e in ("PG", "PGD", "PG3", "WD", "WB")})
 dt = torch.bfloat16
 dev = "cuda"
 print("lib:", L.LIB_PATH)

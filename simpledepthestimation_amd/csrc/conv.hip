@@ -1553,10 +1553,8 @@ static int wgrad_partial(const sde_conv_desc* d, const void* dy, int Cout, int l
     int rps = sde_cdiv(p.g.M, splits);
     rps = sde_cdiv(rps, BR) * BR;
     SDE_CHECK_ARG((long)rps * splits >= p.g.M, "sde_conv_wgrad: split arithmetic");
-    // 1x1 stride-1 layers: 11-16 us against 14-21 us for the register-staged kernel; its 3x3 / strided form measured SLOWER (35-40 vs 27-30 us,
-    // profiles/README.md item 16) and stays behind option value 2
-    const bool wd_one = p.g.KH == 1 && p.g.stride == 1 && p.g.pad == 0;
-    if (g_wgrad_dma && (wd_one || g_wgrad_dma == 2) && sdeconv::wgrad_dma_applicable(p.g, d->dtype, Cout, ldd)) {
+    // 1x1 layers 11-16 us against 14-21 us for the register-staged kernel, 3x3 layers 22-26 us against 27-30 us (profiles/README.md item 16)
+    if (g_wgrad_dma && sdeconv::wgrad_dma_applicable(p.g, d->dtype, Cout, ldd)) {
         sdeconv::wgrad_dma_run(p.g, d->dtype, dy, Cout, ldd, slab, splits, rps, s);
         SDE_CHECK_LAUNCH("sde_conv_wgrad (LDS-DMA)");
         g = p.g;

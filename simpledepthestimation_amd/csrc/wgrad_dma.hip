@@ -27,6 +27,12 @@ typedef __attribute__((address_space(3))) void wd_lds_void;
 
 constexpr int WD_THREADS = 256, WD_PIX = 64, WD_STAGE = 3 * WD_PIX * 128;      // 24 KB: [dY 64 rows][X block 0: 64 rows][X block 1: 64 rows]
 constexpr int WD_L = 6;                                                          // DMA instructions per wave and stage
+#ifndef WD_DEPTH
+// Ring depth (stages); WD_DEPTH - 1 stages of DMA in flight.  Measured (scripts/microbench_conv.py, A/B builds in one call): the 1x1 layers do not care
+// (3 / 4 / 6: 206-299 / 192-300 / 192-302 TFLOP/s), the 3x3 layers do: 264-305 TFLOP/s at depth 3 against 168-195 at 4 or 6 -- two stages (48 KB) of rows
+// in flight still find the neighbouring taps' lines in the 32 KB vector L1 / the XCD's L2 sets, three or five do not.
+#define WD_DEPTH 3
+#endif
 
 struct WDmaP {
     Gather g;
@@ -238,8 +244,8 @@ int wgrad_dma_run(const Gather& g, int dtype, const void* dy, int Cout, int ldd,
     const int kblocks = g.KH * g.KW * (g.Cin / 64);
     const int grid = (Cout / 64) * ((kblocks + 1) / 2) * splits;
     const bool one = g.KH == 1 && g.stride == 1 && g.pad == 0;
-    if (dtype == SDE_F16) { if (one) wd_launch<half_t, true, 4>(p, grid, s); else wd_launch<half_t, false, 4>(p, grid, s); }
-    else { if (one) wd_launch<bf16_t, true, 4>(p, grid, s); else wd_launch<bf16_t, false, 4>(p, grid, s); }
+    if (dtype == SDE_F16) { if (one) wd_launch<half_t, true, WD_DEPTH>(p, grid, s); else wd_launch<half_t, false, WD_DEPTH>(p, grid, s); }
+    else { if (one) wd_launch<bf16_t, true, WD_DEPTH>(p, grid, s); else wd_launch<bf16_t, false, WD_DEPTH>(p, grid, s); }
     return 0;
 }
 
