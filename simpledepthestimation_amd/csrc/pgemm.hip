@@ -563,7 +563,10 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
 static int pg_grid_max(int BM, int BN, int D) {
     const int lds = D * ((BM + BN) * PG_STAGE_K_BYTES + BN * 4);
     const int per_cu = (160 * 1024) / lds;
-    return 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+#ifndef PG_MAX_PER_CU
+#define PG_MAX_PER_CU 4
+#endif
+    return 256 * (per_cu < 1 ? 1 : (per_cu > PG_MAX_PER_CU ? PG_MAX_PER_CU : per_cu));
 }
 
 static bool pg_stats_acc(int tiles_n, int tiles_mn, int ksplit, int src, int BM, int BN, int D) {

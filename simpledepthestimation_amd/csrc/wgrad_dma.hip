@@ -1,5 +1,6 @@
-// Weight gradient on LDS-DMA for the layers with 64-channel-multiple inputs and outputs (every 1x1 and 3x3 convolution of the ResNet
-// encoders; reference: detectron2/layers/resnet_encoder.py:L88-99 and the autograd backward of its nn.Conv2d modules).
+// Weight gradient on LDS-DMA for the layers with 64-channel-multiple inputs and outputs: every 1x1 and 3x3 convolution of the ResNet encoders
+// (reference: detectron2/layers/resnet_encoder.py:L88-99) and the DepthDecoder's reflection-padded and up-sample + concat layers down to 64
+// channels (detectron2/layers/depth_decoder.py:L21-53,L95-110), i.e. the autograd backward of their nn.Conv2d modules.
 //
 //   dW[co][tap][ci] = sum over pixels p of dY[p][co] * X[p + tap][ci]           (one 64 x 128 tile of [Cout][KH*KW*Cin] per workgroup and pixel range)
 //
@@ -86,6 +87,7 @@ __global__ void __launch_bounds__(WD_THREADS) wgrad_dma_kernel(const WDmaP p) {
     const int ns = (mend - mbeg + WD_PIX - 1) / WD_PIX;
 
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(g.x0, (long)g.Bn * g.H0 * g.W0 * g.C0 * 2L);
+    const __amdgpu_buffer_rsrc_t rsk = make_rsrc(g.x1 ? g.x1 : g.x0, g.x1 ? (long)g.Bn * g.IH * g.IW * g.C1 * 2L : 0);      // the skip tensor of an up-sample + concat source
     const __amdgpu_buffer_rsrc_t rsd = make_rsrc(p.dy, (long)g.M * p.ldd * 2L);
 
     // ---- DMA side.  Wave w fills rows 16 w .. 16 w + 15 of each of the three row groups; lane = (row lane >> 3 of a piece, 16-byte slot lane & 7).
@@ -111,7 +113,12 @@ __global__ void __launch_bounds__(WD_THREADS) wgrad_dma_kernel(const WDmaP p) {
         poh[i] = r / g.OW; pow_[i] = r - poh[i] * g.OW;
     }
     // geometry in registers (read from the kernel arguments inside the loop it costs a scalar load + wait per stage on the critical path)
-    const int gs = g.stride, gp = g.pad, IH = g.IH, IW = g.IW, H0 = g.H0, W0 = g.W0, C0 = g.C0, OW = g.OW, OH = g.OH, ldd = p.ldd;
+    const int gs = g.stride, gp = g.pad, IH = g.IH, IW = g.IW, H0 = g.H0, W0 = g.W0, C0 = g.C0, C1 = g.C1, OW = g.OW, OH = g.OH, ldd = p.ldd;
+    const bool refl = g.reflect != 0, upcat = g.mode == SDE_SRC_UPCAT;
+    // up-sample + concat (decoder upconv(i,1), depth_decoder.py:L102-105): K block h lies entirely in the up-sampled x0 (channel < C0: C0 % 64 == 0) or in the skip x1
+    bool hskip[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) hskip[h] = upcat && hc[h] >= C0;
     const int adv_h = WD_PIX / OW, adv_w = WD_PIX - adv_h * OW;      // one stage = 64 pixels further along the row-major pixel order
     int issued = 0;
     auto issue = [&]() {                         // stage `issued` (uniform: every wave issues the same stages)
@@ -130,12 +137,18 @@ __global__ void __launch_bounds__(WD_THREADS) wgrad_dma_kernel(const WDmaP p) {
                     const unsigned o = (unsigned)((m * C0 + hc[h]) * 2) + chunk[i];
                     off = (mok & (hk[h] >= 0)) ? o : kOOB;
                 } else {                         // branch-free: the offset is always computed, the select picks it or the out-of-range value
-                    const int ih = poh[i] * gs - gp + hk[h], iw = pow_[i] * gs - gp + hw_[h];
-                    const bool ok = mok & (hk[h] >= 0) & ((unsigned)ih < (unsigned)IH) & ((unsigned)iw < (unsigned)IW);
-                    const unsigned o = (unsigned)((((pn[i] * H0 + ih) * W0 + iw) * C0 + hc[h]) * 2) + chunk[i];
+                    int ih = poh[i] * gs - gp + hk[h], iw = pow_[i] * gs - gp + hw_[h];
+                    bool ok = mok & (hk[h] >= 0);
+                    if (refl) { ih = reflect1(ih, IH); iw = reflect1(iw, IW); }          // (uniform) ReflectionPad2d(1): every tap has a source pixel
+                    else ok = ok & ((unsigned)ih < (unsigned)IH) & ((unsigned)iw < (unsigned)IW);
+                    unsigned o;
+                    if (hskip[h]) o = (unsigned)((((pn[i] * IH + ih) * IW + iw) * C1 + (hc[h] - C0)) * 2) + chunk[i];
+                    else if (upcat) o = (unsigned)((((pn[i] * H0 + (ih >> 1)) * W0 + (iw >> 1)) * C0 + hc[h]) * 2) + chunk[i];
+                    else o = (unsigned)((((pn[i] * H0 + ih) * W0 + iw) * C0 + hc[h]) * 2) + chunk[i];
                     off = ok ? o : kOOB;
                 }
-                wd_dma16(rsx, slot + (1 + h) * WD_PIX * 128 + i * 1024, off);
+                if (hskip[h]) wd_dma16(rsk, slot + (1 + h) * WD_PIX * 128 + i * 1024, off);
+                else wd_dma16(rsx, slot + (1 + h) * WD_PIX * 128 + i * 1024, off);
             }
             if (!ONE_BY_ONE) {                   // advance this row by one stage (64 pixels)
                 pow_[i] += adv_w; poh[i] += adv_h;
@@ -219,10 +232,12 @@ __global__ void __launch_bounds__(WD_THREADS) wgrad_dma_kernel(const WDmaP p) {
 // ------------------------------------------------------------------------------------------------------------------
 bool wgrad_dma_applicable(const Gather& g, int dtype, int Cout, int ldd) {
     if (!SDE_IS16(dtype)) return false;
-    if (g.mode != SDE_SRC_PLAIN || g.reflect) return false;
-    if (g.Cin % 64 || g.C0 != g.Cin || Cout % 64 || ldd % 8) return false;
+    if (g.mode != SDE_SRC_PLAIN && g.mode != SDE_SRC_UPCAT) return false;
+    if (g.mode == SDE_SRC_UPCAT && !g.reflect) return false;
+    if (g.reflect && (g.pad != 1 || g.IH < 2 || g.IW < 2)) return false;
+    if (g.Cin % 64 || g.C0 % 64 || g.C0 + g.C1 != g.Cin || Cout % 64 || ldd % 8) return false;
     if (g.KH != g.KW || g.KH > 7) return false;
-    if ((long)g.Bn * g.H0 * g.W0 * g.C0 * 2L >= 0x7fffffffL || (long)g.M * ldd * 2L >= 0x7fffffffL) return false;
+    if ((long)g.Bn * g.H0 * g.W0 * g.C0 * 2L >= 0x7fffffffL || (long)g.Bn * g.IH * g.IW * g.C1 * 2L >= 0x7fffffffL || (long)g.M * ldd * 2L >= 0x7fffffffL) return false;
     return true;
 }
 
