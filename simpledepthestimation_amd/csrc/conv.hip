@@ -1580,7 +1580,9 @@ static int launch_wreduce(const sde_wreduce_item* items_in, int n_in, hipStream_
     }
     // streaming form: channels-last gradient, no channel padding, 16-byte aligned slot -> the slab rows ARE gradient rows
     auto streams = [](const sde_wreduce_item& it) {
-        return (it.accumulate & SDE_WREDUCE_OHWI) && it.Cin_pad == it.Cin_real && ((uintptr_t)it.dw & 15) == 0;
+        // (a 1x1 weight is the same memory in either order: torch reports it contiguous, so callers do not flag it channels-last -- the 36 1x1 layers
+        // of ResNet-50 went through the transposing kernel until the timeline showed 0.58 ms of it per step)
+        return ((it.accumulate & SDE_WREDUCE_OHWI) || it.KHW == 1) && it.Cin_pad == it.Cin_real && ((uintptr_t)it.dw & 15) == 0;
     };
     for (int pass = 0; pass < 2; ++pass) {
         sde_wreduce_item sel[WREDUCE_MAX];
