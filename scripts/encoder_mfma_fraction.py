@@ -41,7 +41,7 @@ def run():
 def report(path):
     rows = list(csv.DictReader(open(path)))
     fam = collections.defaultdict(lambda: [0, 0.0])
-    gemm = re.compile(r"pgemm_kernel|halo3_kernel|igemm_kernel|wgrad_kernel|whalo_kernel|chalo_kernel")
+    gemm = re.compile(r"pgemm_kernel|halo3_kernel|igemm_kernel|wgrad_kernel|wgrad_dma_kernel|whalo_kernel|chalo_kernel")
     tot_gemm = tot_all = 0.0
     for r in rows:
         n = r["Kernel_Name"]

@@ -1025,6 +1025,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce_batched_kernel(const WReduce
 // a plain fixed-order sum of float4 rows -- no LDS, no transpose, every access a whole 16-byte group of consecutive lanes.
 // One workgroup = 1024 consecutive floats of one item; same summation order as the kernel above (chunk sums of even / odd rows, four ways).
 __global__ void __launch_bounds__(256) wgrad_sum_batched_kernel(const WReduceBatch batch) {
+    // A workgroup = 64 consecutive float4 columns (1 KB of every slab row) x 4 split lanes (one wave each): lane r sums slabs r, r + 4, r + 8, ...
+    // with four loads in flight, the four partial sums are combined through LDS in a fixed order ((p0 + p1) + (p2 + p3)): bit-reproducible.
+    // (One thread per column walking ALL slabs left the small layers with 16-64 workgroups of serial load chains: 15 us per launch on average,
+    // 120 us for the 64-slab stacks of layer 1; profiles/r02f_sup50_kernel_stats.csv is the state before this form.)
+    __shared__ float4 comb[3][64];
     int lo = 0, hi = batch.n - 1;
     const int b = blockIdx.x;
     while (lo < hi) {
@@ -1034,39 +1039,35 @@ __global__ void __launch_bounds__(256) wgrad_sum_batched_kernel(const WReduceBat
     const WReduceArg it = batch.it[lo];
     const int local = b - (lo ? batch.it[lo - 1].end : 0);
     const size_t total4 = (size_t)it.Cout * it.KHW * it.Cin_pad / 4;
-    const size_t q = (size_t)local * 256 + threadIdx.x;
-    if (q >= total4) return;
-    const int splits = it.splits, chunk = it.chunk & 0x7fff, accumulate = it.Cin_real >> 15;
-    const float4* src = reinterpret_cast<const float4*>(it.slab) + q;
+    const int col = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const size_t q = (size_t)local * 64 + col;
+    const bool live = q < total4;
+    const int splits = it.splits, accumulate = it.Cin_real >> 15;
     auto add4 = [](float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
     const float4 z = {0.f, 0.f, 0.f, 0.f};
     float4 s0 = z, s1 = z, s2 = z, s3 = z;
-    if (chunk == 1) {
-        int sp = 0;
-        for (; sp + 3 < splits; sp += 4) {
-            add4(s0, src[(size_t)sp * total4]); add4(s1, src[(size_t)(sp + 1) * total4]);
-            add4(s2, src[(size_t)(sp + 2) * total4]); add4(s3, src[(size_t)(sp + 3) * total4]);
+    if (live) {
+        const float4* src = reinterpret_cast<const float4*>(it.slab) + q;
+        int sp = r;
+        for (; sp + 12 < splits; sp += 16) {
+            const float4 v0 = src[(size_t)sp * total4], v1 = src[(size_t)(sp + 4) * total4], v2 = src[(size_t)(sp + 8) * total4], v3 = src[(size_t)(sp + 12) * total4];
+            add4(s0, v0); add4(s1, v1); add4(s2, v2); add4(s3, v3);
         }
-        for (; sp < splits; ++sp) add4(s0, src[(size_t)sp * total4]);
-    } else {
-        auto part = [&](int ro) {
-            const int r0 = ro * chunk, r1 = min(splits, r0 + chunk);
-            float4 a = z, c = z;
-            int r = r0;
-            for (; r + 1 < r1; r += 2) { add4(a, src[(size_t)r * total4]); add4(c, src[(size_t)(r + 1) * total4]); }
-            if (r < r1) add4(a, src[(size_t)r * total4]);
-            add4(a, c);
-            return a;
-        };
-        const int rows = (splits + chunk - 1) / chunk;
-        int ro = 0;
-        for (; ro + 3 < rows; ro += 4) { add4(s0, part(ro)); add4(s1, part(ro + 1)); add4(s2, part(ro + 2)); add4(s3, part(ro + 3)); }
-        for (; ro < rows; ++ro) add4(s0, part(ro));
+        for (; sp < splits; sp += 4) add4(s0, src[(size_t)sp * total4]);
     }
     add4(s0, s1); add4(s2, s3); add4(s0, s2);
-    float4* dst = reinterpret_cast<float4*>(it.dw) + q;
-    if (accumulate) { const float4 o = *dst; add4(s0, o); }
-    *dst = s0;
+    if (r > 0) comb[r - 1][col] = s0;
+    __syncthreads();
+    if (r == 0 && live) {
+        float4 p1 = comb[0][col];
+        const float4 p2 = comb[1][col], p3 = comb[2][col];
+        add4(s0, p1);
+        float4 t = p2; add4(t, p3);
+        add4(s0, t);
+        float4* dst = reinterpret_cast<float4*>(it.dw) + q;
+        if (accumulate) { const float4 o = *dst; add4(s0, o); }
+        *dst = s0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1594,7 +1595,7 @@ static int launch_wreduce(const sde_wreduce_item* items_in, int n_in, hipStream_
             int end = 0, need = 0;
             for (int i = 0; i < n; ++i) {
                 const sde_wreduce_item& it = sel[i];
-                end += pass == 0 ? sde_cdiv((long)it.Cout * it.KHW * it.Cin_pad / 4, 256) : it.Cout;
+                end += pass == 0 ? sde_cdiv((long)it.Cout * it.KHW * it.Cin_pad / 4, 64) : it.Cout;
                 const int lds = it.KHW * wreduce_cb(it.KHW, it.Cin_pad, WREDUCE_LDS_FLOATS);
                 if (lds > need) need = lds;
                 const int chunk = it.rows > SDE_WGRAD_FOLD_ROWS ? sde_cdiv(it.rows, SDE_WGRAD_FOLD_ROWS) : 1;
