@@ -224,6 +224,11 @@ int sde_bn_eval_params(const float* gamma, const float* beta, const float* runni
                        sde_stream_t stream);
 /* out = [relu](y*scale + shift [+ residual]) */
 int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu, long M, int C, int dtype, void* out, sde_stream_t stream);
+/* sde_bn_finalize + sde_bn_apply in one launch (same arguments, count = M rows), for 16-bit types, C % 64 == 0 and at most 256 slab rows
+ * (sde_bn_finalize_apply_ok): every workgroup reduces the slab columns of its own 64 channels, redundantly and in a fixed order. */
+int sde_bn_finalize_apply_ok(int tiles, int C, int dtype);
+int sde_bn_finalize_apply(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* bnp, const void* y, const void* residual, int relu, int dtype, void* out, sde_stream_t stream);
 /* BatchNorm(+ReLU, +residual) backward.  The normalised output may have up to three consumers whose gradients arrive separately
  * (dout, dout1, dout2; the latter two may be NULL): they are summed on the fly.  gm [M,C] (workspace, required when relu is set or more than
  * one gradient is given) receives dz = relu'(out) * (sum of the gradients) -- which is also the gradient of the residual input.

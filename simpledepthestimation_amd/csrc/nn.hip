@@ -207,6 +207,86 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
+// BatchNorm finalize + apply in ONE launch for layers whose partial slab is short (<= BNFA_MAX_ROWS rows): a workgroup owns a strip of 64
+// channels (128 bytes of every row, 16-bit types) x a range of rows.  It first reduces the slab columns of ITS 64 channels -- every workgroup of
+// a strip redundantly, in the same fixed order, fp64: identical results everywhere -- into scale / shift held in LDS, then streams its rows.  The
+// workgroups of row range 0 also write bnp (for backward) and update the running statistics.  Saves the separate finalize launch (4.7 us + a kernel
+// boundary, 53 times per ResNet-50 forward pass) at the price of <= 100 KB of L2-resident re-reads per workgroup.
+constexpr int BNFA_MAX_ROWS = 256;
+template <typename T>
+__global__ void __launch_bounds__(256) bn_finalize_apply_kernel(const float* __restrict__ part, int rows, int C, float count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                float momentum, float eps, float* __restrict__ bnp, const T* __restrict__ y,
+                                                                const T* __restrict__ res, int relu, long M, long rows_per_wg, T* __restrict__ out) {
+    constexpr int V = VecOf<T>::V;                       // 8: this kernel is instantiated for the 16-bit types only (64 channels = 8 lanes x 16 B)
+    __shared__ double acc[8][128];
+    __shared__ float ss[2][64];                          // scale, shift of the strip
+    const int strip = blockIdx.x, c0 = strip * 64;
+    const int tid = threadIdx.x;
+    {   // column sums of the strip's 128 floats (sum, sum^2 interleaved) of every slab row: thread = (float4 tid & 31, row lane tid >> 5), eight
+        // independent 16-byte loads per round trip (256 rows = 4 round trips)
+        const int f4 = tid & 31, rl = tid >> 5;
+        const float4* src = reinterpret_cast<const float4*>(part + (size_t)c0 * 2) + f4;
+        const size_t ld4 = (size_t)C / 2;                // float4 per slab row
+        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        int r = rl;
+        for (; r + 56 < rows; r += 64) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(r + 8 * i) * ld4];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                a[0] += v[i].x; a[1] += v[i].y; a[2] += v[i].z; a[3] += v[i].w;
+                b[0] += v[i + 1].x; b[1] += v[i + 1].y; b[2] += v[i + 1].z; b[3] += v[i + 1].w;
+            }
+        }
+        for (; r < rows; r += 8) { const float4 v = src[(size_t)r * ld4]; a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[rl][f4 * 4 + e] = a[e] + b[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int c = c0 + tid;
+        double s1 = 0, s2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1 += acc[i][2 * tid]; s2 += acc[i][2 * tid + 1]; }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rstd, sf = beta[c] - (float)mean * sc;
+        ss[0][tid] = sc; ss[1][tid] = sf;
+        if (blockIdx.y == 0) {
+            bnp[c] = (float)mean; bnp[C + c] = rstd; bnp[2 * C + c] = sc; bnp[3 * C + c] = sf;
+            if (rmean) {   // running statistics: unbiased variance, torch momentum convention
+                const double unb = count > 1.f ? var * count / (count - 1.0) : var;
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+            }
+        }
+    }
+    __syncthreads();
+    const int g8 = tid & 7, rl = tid >> 3;               // 16-byte group inside the strip, row lane (32 rows per pass)
+    float sc[V], sf[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { sc[e] = ss[0][g8 * V + e]; sf[e] = ss[1][g8 * V + e]; }
+    const long r0 = (long)blockIdx.y * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+    for (long r = r0 + rl; r < r1; r += 32) {
+        const long off = r * C + c0 + g8 * V;
+        float v[V], rr[V];
+        load_vec<T>(y + off, v);
+        if (res) load_vec<T>(res + off, rr);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float t = fmaf(v[e], sc[e], sf[e]);          // (bn_bwd_reduce re-derives the ReLU mask from exactly this expression)
+            if (res) t += rr[e];
+            if (relu) t = fmaxf(t, 0.f);
+            v[e] = t;
+        }
+        store_vec<T>(out + off, v);
+    }
+}
+
 // Combine per-thread column accumulators of a 256-thread block whose threads tid, tid+cch, tid+2cch, ... share a 16-byte
 // channel group (cch = groups per row, a divisor of 256).  sh: [256][NV] floats.  Thread t < cch returns the block sums of its
 // group in a[]; no float atomics (deterministic, and LDS float atomics are slow).
@@ -1035,6 +1115,33 @@ int sde_bn_finalize(const float* part, int tiles, int C, long count, const float
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(SLAB_T), 0, (hipStream_t)stream, src, rows, C, (float)count, gamma, beta, running_mean,
                        running_var, momentum, eps, bnp);
     SDE_CHECK_LAUNCH("sde_bn_finalize");
+    return SDE_OK;
+}
+
+int sde_bn_finalize_apply_ok(int tiles, int C, int dtype) { return SDE_IS16(dtype) && C % 64 == 0 && tiles >= 1 && tiles <= BNFA_MAX_ROWS; }
+
+int sde_bn_finalize_apply(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* bnp, const void* y, const void* residual, int relu, int dtype, void* out, sde_stream_t stream) {
+    SDE_CHECK_ARG(part && gamma && beta && bnp && y && out && count > 0, "sde_bn_finalize_apply: bad argument");
+    SDE_CHECK_ARG(sde_bn_finalize_apply_ok(tiles, C, dtype), "sde_bn_finalize_apply: needs a 16-bit type, C %% 64 == 0 and <= %d slab rows (tiles=%d C=%d)",
+                  BNFA_MAX_ROWS, tiles, C);
+    const long M = count;
+    const int strips = C / 64;
+    // enough workgroups to stream at full rate (>= ~1024), rows per workgroup a multiple of the 32-row pass
+    long chunks = (1024 + strips - 1) / strips;
+    long rpw = (M + chunks - 1) / chunks;
+    rpw = (rpw + 31) / 32 * 32;
+    if (rpw < 32) rpw = 32;
+    chunks = (M + rpw - 1) / rpw;
+    const dim3 grid((unsigned)strips, (unsigned)chunks);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SDE_BF16)
+        hipLaunchKernelGGL(bn_finalize_apply_kernel<bf16_t>, grid, dim3(256), 0, s, part, tiles, C, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
+                           bnp, (const bf16_t*)y, (const bf16_t*)residual, relu, M, rpw, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(bn_finalize_apply_kernel<half_t>, grid, dim3(256), 0, s, part, tiles, C, (float)count, gamma, beta, running_mean, running_var, momentum, eps,
+                           bnp, (const half_t*)y, (const half_t*)residual, relu, M, rpw, (half_t*)out);
+    SDE_CHECK_LAUNCH("sde_bn_finalize_apply");
     return SDE_OK;
 }
 

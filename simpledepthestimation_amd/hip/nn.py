@@ -42,6 +42,8 @@ L.register_protos({
     "sde_bn_finalize": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P], c_int),
     "sde_bn_eval_params": ([_P, _P, _P, _P, _F, _I, _P, _P], c_int),
     "sde_bn_apply": ([_P, _P, _P, _I, _LG, _I, _I, _P, _P], c_int),
+    "sde_bn_finalize_apply_ok": ([_I, _I, _I], c_int),
+    "sde_bn_finalize_apply": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P, _P], c_int),
     "sde_reduce_num_blocks": ([_LG, _I], c_int),
     "sde_bn_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _LG, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P], c_int),
     "sde_maxpool_fwd": ([_P, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
@@ -459,6 +461,7 @@ class WGradReducer:
         self.jobs, self._seen = [], set()
 
 
+FUSE_BN_FINALIZE = True  # BatchNorm finalize + apply in one launch where the partial slab is short (A/B: set False)
 WGRAD_DEFER = None      # HipTrainer installs a WGradReducer around backward
 MAIN_STREAM = None      # ... and the stream the backward phase runs on: the side-stream fork / lagging-join bookkeeping assumes ONE main stream
 FOLD_ROWS = 16          # SDE_WGRAD_FOLD_ROWS
@@ -544,14 +547,21 @@ class _BatchNormAct(torch.autograd.Function):
         lib = L.lib()
         dev = y.device
         bnp = torch.empty(4, C, device=dev)
-        if training:
-            L.check(lib.sde_bn_finalize(L.ptr(stats), stats.shape[0] - REDUCE_ROWS, C, M, L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var),
-                                        momentum, eps, L.ptr(bnp), L.stream()), "sde_bn_finalize")
-        else:
-            L.check(lib.sde_bn_eval_params(L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var), eps, C, L.ptr(bnp), L.stream()),
-                    "sde_bn_eval_params")
         out = torch.empty_like(y)
-        L.check(lib.sde_bn_apply(L.ptr(y), L.ptr(bnp), L.ptr(residual), int(relu), M, C, dtype_code(dt), L.ptr(out), L.stream()), "sde_bn_apply")
+        tiles = stats.shape[0] - REDUCE_ROWS if training else 0
+        if training and FUSE_BN_FINALIZE and lib.sde_bn_finalize_apply_ok(tiles, C, dtype_code(dt)):
+            # short partial slabs (one row per persistent workgroup of the producing GEMM): finalize + apply in one launch
+            L.check(lib.sde_bn_finalize_apply(L.ptr(stats), tiles, C, M, L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var),
+                                              momentum, eps, L.ptr(bnp), L.ptr(y), L.ptr(residual), int(relu), dtype_code(dt), L.ptr(out), L.stream()),
+                    "sde_bn_finalize_apply")
+        else:
+            if training:
+                L.check(lib.sde_bn_finalize(L.ptr(stats), tiles, C, M, L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var),
+                                            momentum, eps, L.ptr(bnp), L.stream()), "sde_bn_finalize")
+            else:
+                L.check(lib.sde_bn_eval_params(L.ptr(_f32(gamma)), L.ptr(_f32(beta)), L.ptr(running_mean), L.ptr(running_var), eps, C, L.ptr(bnp), L.stream()),
+                        "sde_bn_eval_params")
+            L.check(lib.sde_bn_apply(L.ptr(y), L.ptr(bnp), L.ptr(residual), int(relu), M, C, dtype_code(dt), L.ptr(out), L.stream()), "sde_bn_apply")
         # backward needs the ReLU mask: with a residual it comes from the saved output; without one sde_bn_bwd re-derives it from y and the
         # BatchNorm parameters (out = NULL), so that tensor is neither kept for backward nor read by it
         ctx.save_for_backward(y, out if (relu and residual is not None) else None, bnp, gamma)

@@ -565,3 +565,46 @@ def test_conv_halo_batchnorm_stats(NN, force_halo):
     y, stats = NN.conv2d(nhwc(x, torch.bfloat16, 8), w.to(dev), None, stride=1, pad=1, bn_stats=True)
     out = NN.batch_norm_act(y, stats, gamma.to(dev), beta.to(dev), torch.zeros(C, device=dev), torch.ones(C, device=dev))
     check(nchw(out, C), o, torch.bfloat16, "bn(halo conv)")
+
+
+@pytest.mark.parametrize("C,R,with_res,relu,dtype", [(256, 192, False, True, torch.bfloat16), (512, 96, True, True, torch.bfloat16), (2048, 23, False, False, torch.bfloat16),
+                                                    (64, 256, True, True, torch.float16), (1024, 1, False, True, torch.bfloat16)])
+def test_bn_finalize_apply_fused_equals_separate(NN, C, R, with_res, relu, dtype):
+    """sde_bn_finalize_apply (one launch; every workgroup re-reduces the slab columns of its 64 channels) against sde_bn_finalize + sde_bn_apply:
+    the same statistics (fp64 sums in a different order: 1e-6), running statistics, and outputs equal up to that."""
+    g = torch.Generator().manual_seed(C + R)
+    M = 37 * R + 11                                        # ragged: not a multiple of the 32-row pass
+    y = (torch.randn(M, C, generator=g) * 1.5 + 0.2).to(dtype)
+    res = torch.randn(M, C, generator=g).to(dtype) if with_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    yf = y.float()
+    bounds = [round(i * M / R) for i in range(R + 1)]
+    stats = torch.zeros(R + NN.REDUCE_ROWS, C, 2)
+    for i in range(R):
+        blk = yf[bounds[i]:bounds[i + 1]]
+        stats[i, :, 0], stats[i, :, 1] = blk.sum(0), (blk * blk).sum(0)
+    outs = {}
+    for fused in (True, False):
+        old, NN.FUSE_BN_FINALIZE = NN.FUSE_BN_FINALIZE, fused
+        try:
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            yd = y.to(dev).view(1, 1, M, C)
+            rd = res.to(dev).view(1, 1, M, C) if with_res else None
+            with torch.no_grad():
+                out = NN.batch_norm_act(yd, stats.to(dev), gamma.to(dev), beta.to(dev), rm, rv, residual=rd, relu=relu)
+            torch.cuda.synchronize()
+            outs[fused] = (out.float().cpu().view(M, C), rm.cpu(), rv.cpu())
+        finally:
+            NN.FUSE_BN_FINALIZE = old
+    (o1, rm1, rv1), (o0, rm0, rv0) = outs[True], outs[False]
+    assert torch.allclose(rm1, rm0, rtol=1e-6, atol=1e-7) and torch.allclose(rv1, rv0, rtol=1e-6, atol=1e-7)
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    bad = ((o1 - o0).abs() > ulp * torch.maximum(o1.abs(), o0.abs()) + 1e-6).sum().item()
+    assert bad == 0, f"{bad} of {o1.numel()} outputs differ by more than one ulp"
+    assert (o1 != o0).float().mean().item() < 1e-3          # and almost all are bit-identical
+    ref = torch.nn.functional.batch_norm(yf, None, None, gamma, beta, True, 0.1, 1e-5)
+    if with_res:
+        ref = ref + res.float()
+    if relu:
+        ref = torch.relu(ref)
+    assert ((o1 - ref).norm() / ref.norm()).item() < (6e-3 if dtype == torch.bfloat16 else 1e-3)
