@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(256) wgrad_sum_batched_kernel(const WReduceBat
     // A workgroup = 64 consecutive float4 columns (1 KB of every slab row) x 4 split lanes (one wave each): lane r sums slabs r, r + 4, r + 8, ...
     // with four loads in flight, the four partial sums are combined through LDS in a fixed order ((p0 + p1) + (p2 + p3)): bit-reproducible.
     // (One thread per column walking ALL slabs left the small layers with 16-64 workgroups of serial load chains: 15 us per launch on average,
-    // 120 us for the 64-slab stacks of layer 1; profiles/r02f_sup50_kernel_stats.csv is the state before this form.)
+    // 120 us for the 64-slab stacks of layer 1; profiles/r02g_sup50_kernel_stats.csv is the state before this form.)
     __shared__ float4 comb[3][64];
     int lo = 0, hi = batch.n - 1;
     const int b = blockIdx.x;

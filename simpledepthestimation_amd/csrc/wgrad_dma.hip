@@ -5,7 +5,7 @@
 //   dW[co][tap][ci] = sum over pixels p of dY[p][co] * X[p + tap][ci]           (one 64 x 128 tile of [Cout][KH*KW*Cin] per workgroup and pixel range)
 //
 // wgrad_kernel (conv.hip) stages both operands through registers and 16-byte ds_write (a third of its LDS cycles are the bank conflicts of
-// those stores, profiles/r02f_sup50_sq_by_kernel.csv) with two barriers per 64-pixel stage.  Here both operands are rows of 128 bytes per
+// those stores, profiles/r02g_sup50_sq_by_kernel.csv) with two barriers per 64-pixel stage.  Here both operands are rows of 128 bytes per
 // pixel -- dY[p][64 co] and X[p + tap][64 ci] -- i.e. exactly the row shape the persistent forward GEMM (pgemm.hip) moves by LDS-DMA:
 //   * a stage = 64 pixels x (64 co | 64 ci of K block 0 | 64 ci of K block 1) = 24 KB, global -> LDS directly (buffer_load_dwordx4 ... lds), a ring of
 //     D stages with D-1 in flight behind a counted s_waitcnt vmcnt and ONE barrier per stage; zero padding, stride and ragged pixel ranges are
