@@ -281,7 +281,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-overlap", action="store_true", help="use the two-phase backward (all-reduce overlap path) even on one GPU")
     ap.add_argument("--no-side-stream", action="store_true", help="weight-gradient GEMMs on the main stream (single-stream graph: profiling aid)")
-    ap.add_argument("--defer-max-mb", type=float, default=None, help="A/B aid: slab stacks up to this size join the phase's batched reduction (hip/lib.py: DEFER_MAX_BYTES)")
+    ap.add_argument("--const", action="append", default=[], metavar="NAME=INT", help="A/B aid: scheduling constant of hip/lib.py (JOIN_LAG, WGRAD_GROUP, DEFER_MAX_BYTES, FORK_MIN_BYTES ...)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sde_conv_set_option(KEY, VALUE) before the model is built (A/B measurements)")
     ap.add_argument("--no-pgemm", action="store_true", help="register-staged GEMM kernels only (A/B against the persistent LDS-DMA GEMM)")
     args = ap.parse_args()
@@ -306,10 +306,14 @@ def main():
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
-    if args.no_side_stream or args.no_pgemm or args.opt or args.defer_max_mb is not None:
+    if args.no_side_stream or args.no_pgemm or args.opt or args.const:
         from simpledepthestimation_amd.hip import lib as L, nn as HN
-        if args.defer_max_mb is not None:
-            L.DEFER_MAX_BYTES = int(args.defer_max_mb * (1 << 20))
+        for kv in args.const:
+            k, v = kv.split("=")
+            assert hasattr(L, k), k
+            setattr(L, k, int(v))
+            if k in ("JOIN_LAG", "WGRAD_GROUP"):
+                L.SCHEDULE_LOCKED = True
         for kv in args.opt:                     # A/B aid: --opt 6=128 -> sde_conv_set_option(SDE_OPT_WGRAD_BLOCKS, 128)
             k, v = kv.split("=")
             HN.set_option(int(k), int(v))

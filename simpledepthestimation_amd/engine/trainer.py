@@ -22,6 +22,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from ..hip import lib as L
 from ..hip import nn as HN
 
 
@@ -75,6 +76,7 @@ class HipTrainer:
     def __init__(self, model, groups, adamw=False, betas=(0.9, 0.999), eps=1e-8, bucket_mb=64, use_graph=False, skip_unused=(".fc.",),
                  adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None, amp=False, init_scale=65536.0, growth_interval=2000):
         self.model = model
+        L.apply_schedule("packnet" if any(type(m).__name__ == "PackNet01" for m in model.modules()) else "resnet")
         self._adam_fn = adam_fn or HN.adam_step      # tests on CPU (gloo) substitute a torch restatement of the same update
         self.adamw, self.betas, self.eps = bool(adamw), betas, float(eps)
         self.use_graph = bool(use_graph)

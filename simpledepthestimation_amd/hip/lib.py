@@ -121,10 +121,26 @@ _side = {}
 # were each decided by an A/B run inside one gpurun call in round 1 (DESIGN.md 6.1 keeps the measurements); the environment switches that
 # selected the losing variants (late join per phase, several side streams, packing on the side stream) were removed with those variants.
 SIDE_STREAM = True      # HipTrainer(side_stream=False) / hip.lib.SIDE_STREAM = False: single-stream backward (profiling, debugging)
-JOIN_LAG = 2            # the main stream joins a group's GEMMs that many convolutions later (0: 9.54, 1: 9.20, 2: 9.01, 3: 9.10 ms/step)
-WGRAD_GROUP = 3         # weight-gradient GEMMs of that many consecutive layers behind one fork (1: 9.22, 2: 8.85, 3: 8.84, 4: 8.91 ms/step)
+JOIN_LAG = 1            # the main stream joins all but the newest JOIN_LAG - 1 groups before it forks the next one
+WGRAD_GROUP = 6         # weight-gradient GEMMs of that many consecutive layers behind one fork
+# The two constants are set per network family when a HipTrainer is built (apply_schedule), from A/B runs inside one gpurun call each:
+#   round 1 (register-staged weight gradients): lag 0 / 1 / 2 / 3 -> 9.54 / 9.20 / 9.01 / 9.10, group 1 / 2 / 3 / 4 -> 9.22 / 8.85 / 8.84 / 8.91 ms/step;
+#   round 2 (LDS-DMA / halo weight gradients, faster slab sums: the side queue got a third shorter), Supervised-R50: (lag, group) = (2, 3) 7.21,
+#   (1, 3) 7.09, (1, 4) 7.10, (1, 5) 7.06, (1, 6) 6.98-7.00, (1, 7) 7.10, (1, 8) 7.00, (1, 10) 7.07, (0, 6) 6.98, (0, 8) 7.00, (2, 8) 7.13;
+#   MonoDepth2-R18 5.48 -> 5.33, R50 8.98 -> 8.74 with (1, 6); PackNet-1A the other way: (2, 3) 53.8, (1, 3) 55.9, (1, 6) 56.0 ms/step.
+SCHEDULES = {"resnet": (1, 6), "packnet": (2, 3)}
+SCHEDULE_LOCKED = False  # bench.py --const JOIN_LAG=... / WGRAD_GROUP=... pins the values for an A/B run
+
+
+def apply_schedule(family):
+    global JOIN_LAG, WGRAD_GROUP
+    if not SCHEDULE_LOCKED:
+        JOIN_LAG, WGRAD_GROUP = SCHEDULES[family]
 GROUP_MAX_BYTES = 128 << 20     # layers with more operand bytes fork alone (PackNet's 190 MB maps: 57.7 vs 60.2 ms/step)
+GROUP_BUDGET_BYTES = 384 << 20  # ... and a group also closes once its layers' operands add up to this much
 DEFER_MAX_BYTES = 2 << 20       # slab stacks up to this size join the phase's batched reduction; bigger ones are summed at once, cache-resident
+FORK_MIN_BYTES = 0              # layers with fewer operand bytes keep their weight-gradient GEMM on the main stream (0: every layer forks; measured
+                                # 10 / 25 / 50 / 100 MB -> 7.52 / 7.93 / 8.77 / 7.78 ms/step against 7.26-7.28 at 0: bench.py --const FORK_MIN_BYTES=...)
 
 
 def side_stream(rotate=True):

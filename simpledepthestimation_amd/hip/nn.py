@@ -260,6 +260,8 @@ class _Conv2d(torch.autograd.Function):
                     meta = dict(M=M, N=Cout, K=KH * KW * (C0 + C1), k=KH, s=stride, mode=int(upcat), splits=splits,
                                 bytes=esz * (B * H0 * W0 * C0 + B * IH * IW * C1 + M * ldy) + 8 * splits * Cout * KH * KW * (C0 + C1))
                 forked = need_dx and L.SIDE_STREAM and L.PROFILE is None
+                if forked and L.FORK_MIN_BYTES:      # (A/B aid, default 0: every layer forks)
+                    forked = (dz.numel() + x0.numel() + (x1.numel() if x1 is not None else 0)) * dz.element_size() >= L.FORK_MIN_BYTES
                 # layers with very large operands (PackNet's full-resolution 64-channel maps: 190 MB each) fork on their own: holding three of
                 # them alive for a group pushes the working set out of the Infinity Cache (PackNet-1A: 60.2 vs 58.4 ms/step when grouped)
                 op_bytes = (dz.numel() + x0.numel() + (x1.numel() if x1 is not None else 0)) * dz.element_size()
@@ -311,7 +313,9 @@ class _Conv2d(torch.autograd.Function):
                                     "sde_conv_wgrad")
                             slab.record_stream(side_g)
                     WGRAD_DEFER.queue.append((launch, (dz, x0, x1, slab, dw)))
-                    if len(WGRAD_DEFER.queue) >= L.WGRAD_GROUP:
+                    WGRAD_DEFER.queue_bytes += op_bytes
+                    # a group closes after WGRAD_GROUP layers or once its operands (kept alive until the group's GEMMs ran) exceed the byte budget
+                    if len(WGRAD_DEFER.queue) >= L.WGRAD_GROUP or WGRAD_DEFER.queue_bytes >= L.GROUP_BUDGET_BYTES:
                         WGRAD_DEFER.run_queue()
                     st["dw"], st["forked"], st["side"] = (None if wslot is not None else dw), False, None
                     return
@@ -403,6 +407,7 @@ class WGradReducer:
         self.forked = False        # some GEMM of this phase still runs on the side stream (late join)
         self.pending = []          # (event behind a layer's side-stream work, its operands) of convolutions whose join is lagging (SDE_JOIN_LAG)
         self.queue = []            # SDE_WGRAD_GROUP > 1: (launch closure, operands) of layers whose weight-gradient GEMM waits for its group's fork
+        self.queue_bytes = 0       # operand bytes held by the queued layers
 
     def run_queue(self):
         """SDE_WGRAD_GROUP > 1: launch the queued weight-gradient GEMMs of the last few layers behind ONE fork of the side stream (one
@@ -420,7 +425,7 @@ class WGradReducer:
         ev = torch.cuda.Event()
         ev.record(side)
         self.pending.append((ev, refs))
-        self.queue = []
+        self.queue, self.queue_bytes = [], 0
 
     def join_pending(self, keep=0):
         """Make the current stream wait for all but the newest `keep` lagging weight-gradient GEMMs and release their operands."""
