@@ -37,7 +37,7 @@ class MonoDepth2Model(HipMetaArch):
         depth_pred, poses = batch["depth_pred"], batch["pose_pred"]
         num_scales = len(depth_pred)
         H, W = image.shape[-2:]
-        losses = defaultdict(lambda: 0)
+        terms = defaultdict(lambda: ([], []))        # loss name -> (per-scale 0-d tensors, their weights)
         photo_losses = []
         for i in range(num_scales):
             scale_w = 1.0 / 2 ** (num_scales - i - 1)
@@ -47,13 +47,18 @@ class MonoDepth2Model(HipMetaArch):
             photo_losses.append(HP.photometric_scale_loss(depth_pred[i], intrinsics, resized_image, resized_targets, poses, w / W, h / H,
                                                           ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2,
                                                           automask=self.use_automask, reduce=self.photometric_reduce, clip=self.clip_loss))
+            def add(name, value, weight):
+                terms[name][0].append(value); terms[name][1].append(weight)
             if self.smooth_loss_w > 0.0:
-                losses["smooth_loss"] += smoothness_loss(depth_pred[i], resized_image) * (scale_w * self.smooth_loss_w / num_scales)
+                add("smooth_loss", smoothness_loss(depth_pred[i], resized_image), scale_w * self.smooth_loss_w / num_scales)
             if self.sup_loss_w > 0.0:
                 # the reference weights this term with smooth_loss_w (MonoDepth2.py:L109, sic)
-                losses["sup_loss"] += self.supervise_loss(depth_pred[i], batch["depth"]) * (scale_w * self.smooth_loss_w / num_scales)
+                add("sup_loss", self.supervise_loss(depth_pred[i], batch["depth"]), scale_w * self.smooth_loss_w / num_scales)
             if self.var_loss_w > 0.0:
-                losses["var_loss"] += variance_loss(depth_pred[i]) * (scale_w * self.var_loss_w / num_scales)
-        output["rec_loss"] = sum(photo_losses) / num_scales
-        output.update(losses)
+                add("var_loss", variance_loss(depth_pred[i]), scale_w * self.var_loss_w / num_scales)
+        # the reference accumulates `loss += term_i * w_i` scale by scale (MonoDepth2.py:L103-112, L126): per loss that is 2 tiny kernels per scale forward
+        # and as many backward; one stack + one dot product with a cached weight vector is the same sum (fp32, 4 terms) in 2 + 1 kernels
+        output["rec_loss"] = self._weighted_sum(photo_losses, [1.0 / num_scales] * num_scales)
+        for name, (vals, ws) in terms.items():
+            output[name] = self._weighted_sum(vals, ws)
         return output

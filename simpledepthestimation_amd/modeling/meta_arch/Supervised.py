@@ -18,9 +18,6 @@ class SupDepthModel(HipMetaArch):
             result["depth_pred"] = scales[0]
             return result
         # the nearest resize of the ground truth to each scale (Supervised.py:L44) happens inside the loss kernel
-        total = None
-        for pred in scales:
-            term = self.loss(pred, result["depth"])
-            total = term if total is None else total + term
-        result["silog_loss"] = total / len(scales)
+        terms = [self.loss(pred, result["depth"]) for pred in scales]
+        result["silog_loss"] = self._weighted_sum(terms, [1.0 / len(scales)] * len(scales))
         return result

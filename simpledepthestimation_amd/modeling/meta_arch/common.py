@@ -19,6 +19,15 @@ class HipMetaArch(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
+    def _weighted_sum(self, values, weights):
+        """sum_i weights[i] * values[i] of 0-d loss tensors as one stack + one dot product with a cached device vector.  The reference accumulates
+        `loss += term_i * w_i` scale by scale: two tiny kernels per scale and loss forward, as many backward."""
+        key = (tuple(float(w) for w in weights), values[0].device, values[0].dtype)
+        cache = self.__dict__.setdefault("_wsum_cache", {})
+        if key not in cache:      # built during the first (eager) step, before any hipGraph capture: no host-to-device copy inside a captured step
+            cache[key] = torch.tensor(key[0], device=key[1], dtype=key[2])
+        return torch.dot(torch.stack([v.reshape(()) for v in values]), cache[key])
+
     def run_depth_net(self, batch):
         """Moves the batch to the model's device and runs the depth network on the fused NHWC input: (img - mean) / std, NCHW -> NHWC,
         channel padding, dtype cast and the optional horizontal flip are ONE kernel (sde_prep_input)."""
