@@ -46,7 +46,11 @@ CONFIGS = {"old": (0, 4, 0, 0), "pg4": (1, 4, 0, 0), "pg3": (1, 3, 0, 0), "pg4+3
            "pg3s": (1, 3, 1, 64064), "pg4s": (1, 4, 1, 64064), "pg3m": (1, 3, 1, 128064), "pg3l": (1, 3, 1, 128128)}      # forced tiles (small / mid / large)
 
 
+SPLITK = int(os.environ.get("MBG_SPLITK", "1"))      # SDE_OPT_SPLITK value for every configuration (>= 2: stage threshold of the 2-way split of 256-511-tile layers)
+
+
 def apply(cfg):
+    HN.set_option(HN.OPT_SPLITK, SPLITK)
     on, depth, t3, tile = CONFIGS[cfg]
     HN.set_option(HN.OPT_PGEMM, on); HN.set_option(HN.OPT_PGEMM_DEPTH, depth); HN.set_option(HN.OPT_PGEMM_3X3, t3); HN.set_option(HN.OPT_PGEMM_TILE, tile)
 

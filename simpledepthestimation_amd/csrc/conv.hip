@@ -1426,6 +1426,10 @@ static int pick_ksplit(const Gather& g, int dtype, int ldy) {
     // 9.73 ms/step, flat between 256 and 1024).  Persistent LDS-DMA kernel: only below one tile per CU (256), towards 512 -- the M = 5760
     // layers (360 tiles) measured 11-22 us unsplit against 18-28 us split three ways (profiles/r02_gemm_microbench.txt).
     const long tmax = pg ? 256 : 384, target = pg ? 512 : 768;
+    // ... and between one and two tiles per CU when K is long (upconv(4,1): 360 tiles x 180 stages run as two uneven waves of workgroups): two ranges.
+    // Measured (scripts/microbench_gemm.py, MBG_SPLITK = threshold): ResNet-50 upconv(4,1) 114 -> 80 us, ResNet-18's (72 stages) 50.6 -> 42.2 us; the
+    // 3x3 256-channel layers (36 stages) get slower when split (23.7 -> 26.9 us), hence 48.  Option values >= 2 set the threshold (A/B).
+    if (pg && tiles >= tmax && tiles < 2 * tmax && nk >= (g_splitk >= 2 ? g_splitk : 48)) return 2;
     if (tiles >= tmax || nk < 16) return 1;
     long S = sde_cdiv(target, tiles);
     if (S > 8) S = 8;
