@@ -446,6 +446,73 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// bn_bwd_finalize + bn_bwd_apply in ONE launch for short partial slabs (<= BNFA_MAX_ROWS rows: the layer3 / layer4 bottleneck BatchNorms), the backward
+// twin of bn_finalize_apply_kernel: a workgroup owns a 64-channel strip x a range of rows, first reduces the slab columns (sum dz, sum dz * xhat) of its
+// own 64 channels -- every workgroup of a strip redundantly, same fixed order, fp64 -- then streams its rows; row range 0 also writes dgamma / dbeta.
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_finalize_apply_kernel(const float* __restrict__ part, int rows, int C, float count, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, int accumulate, const T* __restrict__ dz_in,
+                                                                    const T* __restrict__ y, const float* __restrict__ bnp, long M, long rows_per_wg,
+                                                                    T* __restrict__ dy) {
+    constexpr int V = VecOf<T>::V;
+    __shared__ double acc[8][128];
+    __shared__ float cf[2][64];                          // mean(dz), mean(dz * xhat) of the strip
+    const int c0 = blockIdx.x * 64, tid = threadIdx.x;
+    {
+        const int f4 = tid & 31, rl = tid >> 5;
+        const float4* src = reinterpret_cast<const float4*>(part + (size_t)c0 * 2) + f4;
+        const size_t ld4 = (size_t)C / 2;
+        double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        int r = rl;
+        for (; r + 56 < rows; r += 64) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = src[(size_t)(r + 8 * i) * ld4];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                a[0] += v[i].x; a[1] += v[i].y; a[2] += v[i].z; a[3] += v[i].w;
+                b[0] += v[i + 1].x; b[1] += v[i + 1].y; b[2] += v[i + 1].z; b[3] += v[i + 1].w;
+            }
+        }
+        for (; r < rows; r += 8) { const float4 v = src[(size_t)r * ld4]; a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[rl][f4 * 4 + e] = a[e] + b[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int c = c0 + tid;
+        double s1 = 0, s2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1 += acc[i][2 * tid]; s2 += acc[i][2 * tid + 1]; }
+        cf[0][tid] = (float)(s1 / count); cf[1][tid] = (float)(s2 / count);
+        if (blockIdx.y == 0) {
+            dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+            dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        }
+    }
+    __syncthreads();
+    const int g8 = tid & 7, rl = tid >> 3;
+    float mean[V], rstd[V], sc[V], k1[V], k2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const int c = c0 + g8 * V + e;
+        mean[e] = bnp[c]; rstd[e] = bnp[C + c]; sc[e] = bnp[2 * C + c]; k1[e] = cf[0][g8 * V + e]; k2[e] = cf[1][g8 * V + e];
+    }
+    const long r0 = (long)blockIdx.y * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+    for (long r = r0 + rl; r < r1; r += 32) {
+        const long off = r * C + c0 + g8 * V;
+        float d[V], yv[V], g[V];
+        load_vec<T>(dz_in + off, d);
+        load_vec<T>(y + off, yv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xh = (yv[e] - mean[e]) * rstd[e];
+            g[e] = sc[e] * (d[e] - k1[e] - xh * k2[e]);
+        }
+        store_vec<T>(dy + off, g);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // 3x3 stride-2 pad-1 max-pool (NHWC) with saved arg-max (first maximum in row-major window order, like ATen)
 // ------------------------------------------------------------------------------------------------------------------
@@ -1118,6 +1185,9 @@ int sde_bn_finalize(const float* part, int tiles, int C, long count, const float
     return SDE_OK;
 }
 
+static int g_bn_fuse = 1;       // sde_bn_set_fuse(0): always the separate finalize and apply launches (A/B, tests)
+int sde_bn_set_fuse(int on) { const int old = g_bn_fuse; g_bn_fuse = on ? 1 : 0; return old; }
+
 int sde_bn_finalize_apply_ok(int tiles, int C, int dtype) { return SDE_IS16(dtype) && C % 64 == 0 && tiles >= 1 && tiles <= BNFA_MAX_ROWS; }
 
 int sde_bn_finalize_apply(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -1192,12 +1262,28 @@ int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const voi
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)dout1, (const bf16_t*)dout2, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part, (bf16_t*)gm),
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<half_t>, dim3(nblk), dim3(256), lds, s, (const half_t*)dout, (const half_t*)dout1, (const half_t*)dout2, (const half_t*)out, (const half_t*)y, bnp, relu, M, C, rpb, part, (half_t*)gm));
     SDE_CHECK_LAUNCH("sde_bn_bwd/reduce");
+    const void* dz = gm ? gm : dout;
+    if (g_bn_fuse && SDE_IS16(dtype) && C % 64 == 0 && nblk <= BNFA_MAX_ROWS) {       // short slab: finalize + apply in one launch
+        const int strips = C / 64;
+        long chunks = (1024 + strips - 1) / strips;
+        long rpw = (M + chunks - 1) / chunks;
+        rpw = (rpw + 31) / 32 * 32;
+        chunks = (M + rpw - 1) / rpw;
+        const dim3 grid((unsigned)strips, (unsigned)chunks);
+        if (dtype == SDE_BF16)
+            hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<bf16_t>, grid, dim3(256), 0, s, part, nblk, C, (float)M, dgamma, dbeta, accumulate_params, (const bf16_t*)dz,
+                               (const bf16_t*)y, bnp, M, rpw, (bf16_t*)dy);
+        else
+            hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<half_t>, grid, dim3(256), 0, s, part, nblk, C, (float)M, dgamma, dbeta, accumulate_params, (const half_t*)dz,
+                               (const half_t*)y, bnp, M, rpw, (half_t*)dy);
+        SDE_CHECK_LAUNCH("sde_bn_bwd/finalize+apply");
+        return SDE_OK;
+    }
     int rows = nblk;
     const float* src = pre_reduce(part, rows, 2 * C, s);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(SLAB_T), 0, s, src, rows, C, (float)M, dgamma, dbeta, accumulate_params, coef);
     SDE_CHECK_LAUNCH("sde_bn_bwd/finalize");
     const int nb = grid_for(M * (C / V));
-    const void* dz = gm ? gm : dout;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dz, (const float*)y, bnp, coef, M, C, (float*)dy),
                hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dz, (const bf16_t*)y, bnp, coef, M, C, (bf16_t*)dy),

@@ -43,6 +43,7 @@ L.register_protos({
     "sde_bn_eval_params": ([_P, _P, _P, _P, _F, _I, _P, _P], c_int),
     "sde_bn_apply": ([_P, _P, _P, _I, _LG, _I, _I, _P, _P], c_int),
     "sde_bn_finalize_apply_ok": ([_I, _I, _I], c_int),
+    "sde_bn_set_fuse": ([_I], c_int),
     "sde_bn_finalize_apply": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P, _P], c_int),
     "sde_reduce_num_blocks": ([_LG, _I], c_int),
     "sde_bn_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _LG, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P], c_int),

@@ -608,3 +608,40 @@ def test_bn_finalize_apply_fused_equals_separate(NN, C, R, with_res, relu, dtype
     if relu:
         ref = torch.relu(ref)
     assert ((o1 - ref).norm() / ref.norm()).item() < (6e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
+@pytest.mark.parametrize("C,M,with_res,relu,n_grads", [(256, 5760, False, True, 1), (512, 1440, True, True, 2), (1024, 1445, True, False, 3), (64, 3000, False, True, 1)])
+def test_bn_bwd_finalize_apply_fused_equals_separate(NN, C, M, with_res, relu, n_grads):
+    """sde_bn_bwd with its finalize + apply passes in one launch (short partial slabs) against the three-launch form (sde_bn_set_fuse(0)):
+    dy equal up to one bf16 ulp on a handful of elements, parameter gradients to 1e-6 (fp64 column sums in a different order)."""
+    from simpledepthestimation_amd.hip import lib as L
+    g = torch.Generator().manual_seed(C + M)
+    dt = torch.bfloat16
+    y = (torch.randn(M, C, generator=g) * 1.3 + 0.1).to(dt)
+    res = torch.randn(M, C, generator=g).to(dt) if with_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    yf = y.float()
+    stats = torch.zeros(1 + NN.REDUCE_ROWS, C, 2)
+    stats[0, :, 0], stats[0, :, 1] = yf.sum(0), (yf * yf).sum(0)
+    grads = [torch.randn(M, C, generator=g).to(dt) for _ in range(n_grads)]
+    outs = {}
+    for fuse in (1, 0):
+        old = L.lib().sde_bn_set_fuse(fuse)
+        try:
+            yd = y.to(dev).view(1, 1, M, C).requires_grad_(True)
+            rd = res.to(dev).view(1, 1, M, C).requires_grad_(True) if with_res else None
+            gd, bd = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+            o = NN.batch_norm_act(yd, stats.to(dev), gd, bd, torch.zeros(C, device=dev), torch.ones(C, device=dev), residual=rd, relu=relu, n_out=n_grads)
+            o = o if isinstance(o, tuple) else (o,)
+            torch.autograd.backward(list(o), [gr.to(dev).view(1, 1, M, C) for gr in grads])
+            torch.cuda.synchronize()
+            outs[fuse] = (yd.grad.float().cpu().view(M, C), gd.grad.cpu(), bd.grad.cpu(), rd.grad.float().cpu().view(M, C) if with_res else None)
+        finally:
+            L.lib().sde_bn_set_fuse(old)
+    (dy1, dg1, db1, dr1), (dy0, dg0, db0, dr0) = outs[1], outs[0]
+    assert torch.allclose(dg1, dg0, rtol=1e-6, atol=1e-6) and torch.allclose(db1, db0, rtol=1e-6, atol=1e-6)
+    bad = ((dy1 - dy0).abs() > 2.0 ** -7 * torch.maximum(dy1.abs(), dy0.abs()) + 1e-6).sum().item()
+    assert bad == 0, f"{bad} of {dy1.numel()} elements of dy differ by more than one bf16 ulp"
+    assert (dy1 != dy0).float().mean().item() < 1e-3
+    if with_res:
+        assert torch.equal(dr1, dr0)
