@@ -90,6 +90,14 @@ int sde_photo_fwd(const sde_photo_desc* d, float* const* sampled, uint8_t* sel, 
 int sde_photo_bwd(const sde_photo_desc* d, const float* const* sampled, const uint8_t* sel, const float* gout, float gscale, float* d_depth,
                   int accumulate_depth, float* pose_partial, float* const* d_pose, int accumulate_pose, sde_stream_t stream);
 
+/* Stand-alone SSIM distance map, the callable module of detectron2/modeling/losses/ssim_loss.py:L6-53:
+ * out[b,c,h,w] = clamp((1 - SSIM(x, y)) / 2, 0, 1) with ReflectionPad2d(1) + 3x3 mean; x, y, out planar [B,C,H,W] fp32 (the training path
+ * evaluates SSIM inside sde_photo_fwd / sde_photo_bwd).  Backward: dx and/or dy (either may be NULL) for the upstream gradient gout [B,C,H,W];
+ * coef_ws: [B*C*H*W][4] floats of workspace, 16-byte aligned. */
+int sde_ssim_fwd(const float* x, const float* y, int B, int C, int H, int W, float C1, float C2, float* out, sde_stream_t stream);
+int sde_ssim_bwd(const float* x, const float* y, const float* gout, int B, int C, int H, int W, float C1, float C2, float* coef_ws, float* dx, float* dy,
+                 sde_stream_t stream);
+
 /* detectron2/modeling/losses/smoothness_loss.py:L42-80.  depth [B,1,h,w], img [B,3,h,w].
  * mean_part [B*32], dn [B,h,w], loss_part/s_part [sde_smooth_num_blocks] are caller workspaces that backward re-reads.
  * loss_out[0] (+)= loss_scale * smoothness_loss. */

@@ -4,7 +4,8 @@ detectron2/data/preprocess/augmentation.py and datasets/kitti_v2.py cannot be im
 oracle/gen_golden_eval.py -- the definitions that need none of them are compiled, unmodified, from the files' syntax trees into a namespace
 holding numpy / random / torch and stand-ins for the registry decorator and the two base classes:
   augmentation.py: resize_depth, KBCrop, CropTopTo, RandomCrop (forward), RandomFlip, ClipDepth        (L14-24, L27-120, L170-240)
-  kitti_v2.py:     KittiDepthV2 (split parsing, existence / context filtering, calibration, sample dict, batch_collator)   (L15-221)
+  kitti_v2.py:     KittiDepthV2 (split parsing, existence / context filtering, calibration, sample dict, batch_collator, WITH_POSE)   (L15-221)
+  geometry/pose_utils.py: rot{x,y,z}_np, OxtsPacket, pose_from_oxts_packet_np, T_from_R_t_np, invert_pose_np, euler2mat, invert_pose   (L7-127, L140-145)
 `np.int` (removed from numpy >= 1.24, used at augmentation.py:L22-23) is provided by the namespace's numpy proxy, as numpy 1.19 (the pinned
 version, requirements.txt) defined it: the builtin int.
 The KITTI directory tree the reader walks is synthetic and rebuilt identically by tests/test_data.py (make_kitti_tree below).
@@ -53,8 +54,14 @@ class Cfg(dict):
 
 def _compile(path, names, ns):
     tree = ast.parse(open(path).read(), path)
-    keep = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
-    assert sorted(n.name for n in keep) == sorted(names), [n.name for n in keep]
+    def name(n):
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+            return n.name
+        if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name):      # module constants (OxtsPacket)
+            return n.targets[0].id
+        return None
+    keep = [n for n in tree.body if name(n) in names]
+    assert sorted(name(n) for n in keep) == sorted(names), [name(n) for n in keep]
     exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
     return ns
 
@@ -67,9 +74,16 @@ def reference_preprocess():
     return _compile(os.path.join(REF, "preprocess", "augmentation.py"), ("resize_depth", "KBCrop", "CropTopTo", "RandomCrop", "RandomFlip", "ClipDepth"), ns)
 
 
+def reference_pose_utils():
+    ns = {"np": np, "torch": torch, "namedtuple": collections.namedtuple}
+    return _compile(os.path.join(os.path.dirname(REF), "geometry", "pose_utils.py"),
+                    ("rotx_np", "roty_np", "rotz_np", "OxtsPacket", "pose_from_oxts_packet_np", "T_from_R_t_np", "invert_pose_np", "euler2mat", "invert_pose"), ns)
+
+
 def reference_dataset():
+    pu = reference_pose_utils()
     ns = {"np": np, "os": os, "torch": torch, "defaultdict": collections.defaultdict, "logger": logging.getLogger("ref"), "DATASET_REGISTRY": _Reg(),
-          "DatasetBase": _DatasetBase}
+          "DatasetBase": _DatasetBase, "pose_from_oxts_packet_np": pu["pose_from_oxts_packet_np"], "T_from_R_t_np": pu["T_from_R_t_np"]}
     return _compile(os.path.join(REF, "datasets", "kitti_v2.py"), ("KittiDepthV2",), ns)["KittiDepthV2"]
 
 
@@ -88,7 +102,7 @@ def make_kitti_tree(root):
     """A miniature KITTI raw + refined-depth tree: two dates, three drives, frames with holes (so context filtering bites), one missing depth
     file, a second camera, and the split file.  Images 12 x 40 RGB, depth 16-bit PNGs.  Deterministic."""
     from PIL import Image
-    r = np.random.default_rng(42)
+    r, ro = np.random.default_rng(42), np.random.default_rng(43)          # ro: the OXTS packets (their own stream: the images keep their values)
     drives = [("2011_09_26", "0001", [0, 1, 2, 3, 5, 6, 7]), ("2011_09_26", "0002", [10, 11, 12]), ("2011_09_28", "0001", [0, 1, 2, 4])]
     entries = []
     for date, drive, frames in drives:
@@ -101,7 +115,20 @@ def make_kitti_tree(root):
             f.write(f"P_rect_03: {base:e} 0.000000e+00 6.095593e+02 -3.395242e+02 0.000000e+00 {base:e} 1.728540e+02 2.199936e+00 0.000000e+00 0.000000e+00 1.000000e+00 2.729905e-03\n")
         for name in ("calib_velo_to_cam.txt", "calib_imu_to_velo.txt"):       # read (and, without WITH_POSE, ignored) by the reference's __getitem__
             with open(os.path.join(root, "raw", date, name), "w") as f:
-                f.write("calib_time: 15-Mar-2012 11:37:16\nR: 1 0 0 0 1 0 0 0 1\nT: 0.1 0.2 0.3\n")
+                if name == "calib_velo_to_cam.txt":
+                    f.write("calib_time: 15-Mar-2012 11:37:16\nR: 7.533745e-03 -9.999714e-01 -6.166020e-04 1.480249e-02 7.280733e-04 -9.998902e-01 9.998621e-01 "
+                            "7.523790e-03 1.480755e-02\nT: -4.069766e-03 -7.631618e-02 -2.717806e-01\n")
+                else:
+                    f.write("calib_time: 25-May-2012 16:47:16\nR: 9.999976e-01 7.553071e-04 -2.035826e-03 -7.854027e-04 9.998898e-01 -1.482298e-02 2.024406e-03 "
+                            "1.482454e-02 9.998881e-01\nT: -8.086759e-01 3.195559e-01 -7.997231e-01\n")
+        op = os.path.join(root, "raw", date, f"{date}_drive_{drive}_sync", "oxts", "data")
+        os.makedirs(op, exist_ok=True)
+        lat, lon, alt, yaw = 49.0 + ro.random() * 0.03, 8.4 + ro.random() * 0.05, 110.0 + ro.random() * 10, ro.uniform(-3.0, 3.0)
+        for fr in range(0, max(frames) + 1):         # a packet per frame from the drive's first one (the origin of the odometry poses)
+            lat, lon, alt, yaw = lat + ro.normal() * 2e-6, lon + ro.normal() * 3e-6, alt + ro.normal() * 0.02, yaw + ro.normal() * 0.01
+            vals = [lat, lon, alt, ro.normal() * 0.03, ro.normal() * 0.03, yaw] + list(ro.normal(size=19)) + [4, 10, 4, 4, 0]
+            with open(os.path.join(op, f"{fr:010d}.txt"), "w") as f:
+                f.write(" ".join(f"{v:.12f}" if i < 25 else str(v) for i, v in enumerate(vals)) + "\n")
         for cam in ("image_02", "image_03"):
             for fr in frames:
                 img_id = f"{fr:010d}"
@@ -175,6 +202,8 @@ def main():
             out[f"ds.{tag}.item_meta"] = np.array([json.dumps({k: (v if not isinstance(v, str) else os.path.relpath(v, tmp) if v.startswith(tmp) else v) if not isinstance(v, list)
                                                                else [os.path.relpath(x, tmp) if x.startswith(tmp) else x for x in v]
                                                                for k, v in it["metadata"].items()}, sort_keys=True) for it in items])
+        ds = Ref(dataset_cfg(raw, depth, split, WITH_POSE=True, FORWARD_CONTEXT=0, BACKWARD_CONTEXT=0), None)
+        out["ds.pose.pose_gt"] = np.stack([ds[i]["pose_gt"] for i in range(len(ds))])
         # batch_collator on synthetic sample dicts of the shapes the chain produces
         ds = Ref(dataset_cfg(raw, depth, split), None)
         g = torch.Generator().manual_seed(3)
@@ -190,6 +219,19 @@ def main():
         out["collate.img_shape"] = np.array(b["img"].shape); out["collate.depth"] = b["depth"].numpy(); out["collate.K"] = b["intrinsics"].numpy()
         out["collate.ctx_img0"] = b["ctx_img"][0]; out["collate.ctx_img1"] = b["ctx_img"][1]; out["collate.ctx_depth1"] = b["ctx_depth"][1]
         out["collate.ctx_img_orig1"] = b["ctx_img_orig"][1]; out["collate.flip"] = np.array(b["flip"]); out["collate.n_meta"] = np.int64(len(b["metadata"]))
+    # ---- geometry/pose_utils.py on seeded values
+    pu = reference_pose_utils()
+    r = np.random.default_rng(21)
+    out["pu.angles"] = r.uniform(-3.0, 3.0, (6, 3)).astype(np.float32)
+    out["pu.euler2mat"] = pu["euler2mat"](torch.from_numpy(out["pu.angles"])).numpy()
+    T = np.stack([pu["T_from_R_t_np"](pu["rotz_np"](a[2]).dot(pu["roty_np"](a[1]).dot(pu["rotx_np"](a[0]))), r.normal(size=3) * 5) for a in out["pu.angles"].astype(np.float64)])
+    out["pu.T"] = T
+    out["pu.invert_pose_np"] = np.stack([pu["invert_pose_np"](t) for t in T])
+    out["pu.invert_pose"] = pu["invert_pose"](torch.from_numpy(T.astype(np.float32))).numpy()
+    packets = np.concatenate([np.stack([r.uniform(-80, 80, 4), r.uniform(-180, 180, 4), r.uniform(0, 500, 4)], 1), r.uniform(-3, 3, (4, 3)), r.normal(size=(4, 24))], 1)
+    out["pu.packets"] = packets
+    Rt = [pu["pose_from_oxts_packet_np"](p, np.cos(p[0] * np.pi / 180.0)) for p in packets]
+    out["pu.oxts_R"] = np.stack([x[0] for x in Rt]); out["pu.oxts_t"] = np.stack([x[1] for x in Rt])
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(out), "arrays")
 

@@ -503,6 +503,85 @@ __global__ void __launch_bounds__(BT_N) photo_bwd_kernel(PhotoBwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stand-alone SSIM distance map (the callable module of ssim_loss.py:L6-53): out = clamp((1 - SSIM(x, y)) / 2, 0, 1) per pixel and channel,
+// ReflectionPad2d(1) + 3x3 mean, planar [B*C][H][W] fp32.  The training path evaluates SSIM inside photo_fwd / photo_bwd; this is the operator
+// surface for callers of the module itself.  Backward: per window the four coefficients of d(out)/d(window sums) -- cAx, cAy (means), cB
+// (second moments), cC (cross moment) -- then every pixel gathers the up to nine windows that contain it, with the multiplicity the
+// reflection gives border taps.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ssim_map_kernel(const float* __restrict__ x, const float* __restrict__ y, int planes, int H, int W, float C1, float C2,
+                                                       float* __restrict__ out, const float* __restrict__ gout, float* __restrict__ coef) {
+#pragma clang fp contract(fast)
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    for (int p = blockIdx.z; p < planes; p += gridDim.z) {
+        const float* xs = x + (long)p * H * W;
+        const float* ys = y + (long)p * H * W;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int ry = reflect_idx(py + dy, H);
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int rx = reflect_idx(px + dx, W);
+                const float a = xs[(long)ry * W + rx], b = ys[(long)ry * W + rx];
+                sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+            }
+        }
+        const long o = ((long)p * H + py) * W + px;
+        if (out) out[o] = ssim_from_moments(sx, sy, sxx, syy, sxy, C1, C2);
+        if (coef) {
+            const float inv9 = 1.0f / 9.0f;
+            const float mx = sx * inv9, my = sy * inv9, exx = sxx * inv9, eyy = syy * inv9, exy = sxy * inv9;
+            const float n1 = 2.0f * mx * my + C1, n2 = 2.0f * (exy - mx * my) + C2;
+            const float d1 = mx * mx + my * my + C1, d2 = (exx - mx * mx) + (eyy - my * my) + C2;
+            const float n = n1 * n2, dn = d1 * d2, rdn = __builtin_amdgcn_rcpf(dn);
+            const float l = (1.0f - n * rdn) * 0.5f;
+            float cAx = 0.f, cAy = 0.f, cB = 0.f, cC = 0.f;
+            if (l >= 0.f && l <= 1.f) {                                  // clamp passes the gradient on [0, 1] only
+                const float f = -0.5f * gout[o] * inv9;                    // d out / d SSIM, folded with the 1/9 of the box filter
+                const float dd = 2.0f * (d2 - d1);
+                cAx = f * (2.0f * my * (n2 - n1) * dn - n * dd * mx) * (rdn * rdn);
+                cAy = f * (2.0f * mx * (n2 - n1) * dn - n * dd * my) * (rdn * rdn);
+                cB = f * (-n * d1) * (rdn * rdn);
+                cC = f * (2.0f * n1) * rdn;
+            }
+            reinterpret_cast<float4*>(coef)[o] = make_float4(cAx, cAy, cB, cC);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ssim_bwd_gather_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ coef, int planes,
+                                                              int H, int W, float* __restrict__ dx, float* __restrict__ dy) {
+#pragma clang fp contract(fast)
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    for (int p = blockIdx.z; p < planes; p += gridDim.z) {
+        const long o = ((long)p * H + py) * W + px;
+        const float xv = x[o], yv = y[o];
+        float gx = 0.f, gy = 0.f;
+#pragma unroll
+        for (int ey = -1; ey <= 1; ++ey) {
+            const int wy = py + ey;
+            if (wy < 0 || wy >= H) continue;
+            const float my_ = ((py == 1 && ey == -1) || (py == H - 2 && ey == 1)) ? 2.f : 1.f;      // the window's reflected row is this row again
+#pragma unroll
+            for (int ex = -1; ex <= 1; ++ex) {
+                const int wx = px + ex;
+                if (wx < 0 || wx >= W) continue;
+                const float mx_ = ((px == 1 && ex == -1) || (px == W - 2 && ex == 1)) ? 2.f : 1.f;
+                const float4 c = reinterpret_cast<const float4*>(coef)[((long)p * H + wy) * W + wx];
+                const float m = my_ * mx_;
+                gx += m * (c.x + 2.0f * xv * c.z + yv * c.w);
+                gy += m * (c.y + 2.0f * yv * c.z + xv * c.w);
+            }
+        }
+        if (dx) dx[o] = gx;
+        if (dy) dy[o] = gy;
+    }
+}
+
 // Sum per-block pose partials of each sample into d_pose [NCTX][B][4][4] (last row zero).
 __global__ void pose_grad_finalize_kernel(const float* __restrict__ partial, int blocks_per_sample, int nctx, int B,
                                           float* __restrict__ dpose0, float* __restrict__ dpose1, float* __restrict__ dpose2,
@@ -879,6 +958,28 @@ int sde_photo_bwd(const sde_photo_desc* d, const float* const* sampled, const ui
                        d_pose[0], d->nctx > 1 ? d_pose[1] : nullptr, d->nctx > 2 ? d_pose[2] : nullptr, d->nctx > 3 ? d_pose[3] : nullptr,
                        accumulate_pose);
     SDE_CHECK_LAUNCH("sde_photo_bwd/finalize");
+    return SDE_OK;
+}
+
+int sde_ssim_fwd(const float* x, const float* y, int B, int C, int H, int W, float C1, float C2, float* out, sde_stream_t stream) {
+    SDE_CHECK_ARG(x && y && out && B > 0 && C > 0 && H >= 2 && W >= 2, "sde_ssim_fwd: bad argument (B=%d C=%d H=%d W=%d)", B, C, H, W);
+    const int planes = B * C;
+    dim3 grid(sde_cdiv(W, 64), sde_cdiv(H, 4), planes < 64 ? planes : 64);
+    hipLaunchKernelGGL(ssim_map_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, planes, H, W, C1, C2, out, (const float*)nullptr, (float*)nullptr);
+    SDE_CHECK_LAUNCH("sde_ssim_fwd");
+    return SDE_OK;
+}
+
+int sde_ssim_bwd(const float* x, const float* y, const float* gout, int B, int C, int H, int W, float C1, float C2, float* coef_ws, float* dx, float* dy,
+                 sde_stream_t stream) {
+    SDE_CHECK_ARG(x && y && gout && coef_ws && (dx || dy) && B > 0 && C > 0 && H >= 2 && W >= 2, "sde_ssim_bwd: bad argument (B=%d C=%d H=%d W=%d)", B, C, H, W);
+    SDE_CHECK_ARG(((uintptr_t)coef_ws & 15) == 0, "sde_ssim_bwd: coef_ws must be 16-byte aligned");
+    const int planes = B * C;
+    dim3 grid(sde_cdiv(W, 64), sde_cdiv(H, 4), planes < 64 ? planes : 64);
+    hipLaunchKernelGGL(ssim_map_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, planes, H, W, C1, C2, (float*)nullptr, gout, coef_ws);
+    SDE_CHECK_LAUNCH("sde_ssim_bwd/coefficients");
+    hipLaunchKernelGGL(ssim_bwd_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, coef_ws, planes, H, W, dx, dy);
+    SDE_CHECK_LAUNCH("sde_ssim_bwd/gather");
     return SDE_OK;
 }
 

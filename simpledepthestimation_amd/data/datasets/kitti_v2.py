@@ -4,7 +4,7 @@ On-disk formats: the split file lists ``<date>/<date>_drive_<drive>_sync/<cam>/d
 are 8-bit PNGs; ``calib_cam_to_cam.txt`` holds ``key: v0 v1 ...`` lines, ``P_rect_0<cam digit>`` (3x4, row-major) gives the intrinsics K;
 depth ground truth is a 16-bit PNG (or a velodyne .npz).  A sample survives only if its files exist, and -- with FORWARD_CONTEXT /
 BACKWARD_CONTEXT -- if its neighbours at +-STRIDE frames of the same drive and camera are in the list.
-WITH_POSE (OXTS odometry) is not on the path (false in every config of the two projects): it raises."""
+WITH_POSE adds data['pose_gt'], the OXTS odometry pose relative to the drive's first frame (false in every config of the two projects)."""
 import logging
 import os
 from collections import defaultdict
@@ -12,6 +12,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
+from ...geometry import pose_utils as PU
 from ..build import DATASET_REGISTRY, DatasetBase
 
 logger = logging.getLogger(__name__)
@@ -49,9 +50,7 @@ class KittiDepthV2(DatasetBase):
         self.forward_context = dataset_cfg.get("FORWARD_CONTEXT", 0)
         self.backward_context = dataset_cfg.get("BACKWARD_CONTEXT", 0)
         self.stride = dataset_cfg.get("STRIDE", 0)
-        self.with_pose = dataset_cfg.get("WITH_POSE", False)
-        if self.with_pose:
-            raise NotImplementedError("WITH_POSE (OXTS odometry ground truth) is outside the hot path: false in every config of the two projects")
+        self.with_pose = dataset_cfg.get("WITH_POSE", False)     # OXTS odometry ground truth as data['pose_gt'] (false in every config of the two projects)
 
         metas, count = [], 0
         for line in open(self.split_file, "r"):
@@ -105,7 +104,33 @@ class KittiDepthV2(DatasetBase):
                              "ctx_img_dir": [self._get_img_dir(*m) for m in ctx], "ctx_depth_dir": [self._get_depth_dir(*m) for m in ctx],
                              "ctx_lidar_dir": [self._get_lidar_dir(*m) for m in ctx]},
                 "intrinsics": self.intrinsics(date, cam)}
+        if self.with_pose:
+            data["pose_gt"] = self._get_pose(date, drive, img_id)
         return self.preprocess(data)
+
+    def _get_oxts_dir(self, date, drive, img_id):
+        return os.path.join(self.data_root, date, f"{date}_drive_{drive}_sync", "oxts", "data", f"{img_id}.txt")
+
+    def _imu2cam(self, date):
+        """Rectified camera-0 frame <- IMU: R_rect_00 @ velo_to_cam @ imu_to_velo (kitti_v2.py:L123-131)."""
+        key = (date, "imu2cam")
+        if key not in self.calib_cache:
+            R0 = np.eye(4, dtype=np.float32)
+            R0[:3, :3] = read_calib(os.path.join(self.data_root, date, "calib_cam_to_cam.txt"))["R_rect_00"].reshape([3, 3])
+            velo = read_calib(os.path.join(self.data_root, date, "calib_velo_to_cam.txt"))
+            imu = read_calib(os.path.join(self.data_root, date, "calib_imu_to_velo.txt"))
+            self.calib_cache[key] = R0 @ PU.T_from_R_t_np(velo["R"], velo["T"]) @ PU.T_from_R_t_np(imu["R"], imu["T"])
+        return self.calib_cache[key]
+
+    def _get_pose(self, date, drive, img_id):
+        """Camera pose relative to the drive's first frame from the OXTS packets (kitti_v2.py:L178-195): the Mercator scale is fixed by the first
+        frame's latitude, poses are expressed in the rectified camera frame through imu2cam."""
+        origin = np.loadtxt(self._get_oxts_dir(date, drive, "0000000000"), delimiter=" ", skiprows=0)
+        scale = np.cos(origin[0] * np.pi / 180.0)
+        origin_pose = PU.T_from_R_t_np(*PU.pose_from_oxts_packet_np(origin, scale))
+        pose = PU.T_from_R_t_np(*PU.pose_from_oxts_packet_np(np.loadtxt(self._get_oxts_dir(date, drive, img_id), delimiter=" ", skiprows=0), scale))
+        imu2cam = self._imu2cam(date)
+        return (imu2cam @ np.linalg.inv(origin_pose) @ pose @ np.linalg.inv(imu2cam)).astype(np.float32)
 
     def _get_img_dir(self, date, drive, cam, img_id):
         return os.path.join(self.data_root, date, f"{date}_drive_{drive}_sync", cam, "data", f"{img_id}.png")

@@ -193,6 +193,40 @@ def smoothness_loss(depth, image):
     return _Smooth.apply(depth, image)
 
 
+class _SSIMMap(torch.autograd.Function):
+    """The stand-alone SSIM distance map (ssim_loss.py:L34-53) with gradients to both images."""
+
+    @staticmethod
+    def forward(ctx, x, y, C1, C2):
+        x, y = _f32c(x), _f32c(y)
+        if x.shape != y.shape or x.dim() != 4:
+            raise L.SdeHipError(f"SSIM: x and y must be [B,C,H,W] of one shape, got {tuple(x.shape)} and {tuple(y.shape)}")
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        L.check(L.lib().sde_ssim_fwd(L.ptr(x), L.ptr(y), B, C, H, W, C1, C2, L.ptr(out), L.stream()), "sde_ssim_fwd")
+        ctx.save_for_backward(x, y)
+        ctx.cfg = (C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        C1, C2 = ctx.cfg
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if dx is None and dy is None:
+            return None, None, None, None
+        ws = torch.empty(B * C * H * W, 4, device=x.device)
+        L.check(L.lib().sde_ssim_bwd(L.ptr(x), L.ptr(y), L.ptr(_f32c(gout)), B, C, H, W, C1, C2, L.ptr(ws), L.ptr(dx), L.ptr(dy), L.stream()), "sde_ssim_bwd")
+        return dx, dy, None, None
+
+
+def ssim_map(x, y, C1=1e-4, C2=9e-4):
+    """clamp((1 - SSIM(x, y)) / 2, 0, 1) per pixel and channel, [B,C,H,W] fp32 (ssim_loss.py:L34-53)."""
+    return _SSIMMap.apply(x, y, float(C1), float(C2))
+
+
 class _Silog(torch.autograd.Function):
     @staticmethod
     def forward(ctx, est, gt, vf):

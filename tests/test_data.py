@@ -220,3 +220,35 @@ def test_loaders_produce_the_batch_dict_contract(tree):
     pf = list(DevicePrefetcher(batches, "cpu"))
     assert len(pf) == len(batches) and torch.equal(pf[0]["img"], batches[0]["img"]) and torch.is_tensor(pf[0]["ctx_img"][0]) and pf[0]["flip"] == batches[0]["flip"]
     assert list(InferenceSampler(5)) == [0, 1, 2, 3, 4]
+
+
+def test_pose_utils_numpy_and_torch_vs_reference(gd):
+    """geometry/pose_utils.py: OXTS packet -> (R, t) (Mercator), homogeneous transforms and their inverses vs the reference's functions."""
+    from simpledepthestimation_amd.geometry import pose_utils as PU
+    for p, R, t in zip(gd["pu.packets"], gd["pu.oxts_R"], gd["pu.oxts_t"]):
+        R2, t2 = PU.pose_from_oxts_packet_np(p, np.cos(p[0] * np.pi / 180.0))
+        assert np.array_equal(R2, R) and np.array_equal(t2, t)
+    with pytest.raises(ValueError):
+        PU.pose_from_oxts_packet_np(gd["pu.packets"][0][:7], 1.0)
+    for T, Ti in zip(gd["pu.T"], gd["pu.invert_pose_np"]):
+        mine = PU.invert_pose_np(T)
+        assert np.allclose(mine, Ti, rtol=0, atol=1e-15) and np.allclose(mine @ T, np.eye(4), atol=1e-12)
+        assert np.array_equal(PU.T_from_R_t_np(T[:3, :3].copy(), T[:3, 3].copy()), T)
+    Tt = torch.from_numpy(gd["pu.T"].astype(np.float32))
+    assert torch.allclose(PU.invert_pose(Tt), torch.from_numpy(gd["pu.invert_pose"]), rtol=0, atol=1e-6)
+    a = 0.3
+    assert np.allclose(PU.rotx_np(a) @ [0, 1, 0], [0, np.cos(a), np.sin(a)]) and np.allclose(PU.roty_np(a) @ [0, 0, 1], [np.sin(a), 0, np.cos(a)])
+    assert np.allclose(PU.rotz_np(a) @ [1, 0, 0], [np.cos(a), np.sin(a), 0])
+
+
+def test_kitti_dataset_with_pose_vs_reference(gd, tree):
+    """WITH_POSE: data['pose_gt'] = imu2cam @ inv(origin) @ pose @ inv(imu2cam) from the OXTS packets and the three calibration files."""
+    root, (raw, depth, split) = tree
+    ds = DATASET_REGISTRY.get("KittiDepthV2")(dataset_cfg(raw, depth, split, WITH_POSE=True, FORWARD_CONTEXT=0, BACKWARD_CONTEXT=0), None)
+    poses = np.stack([ds[i]["pose_gt"] for i in range(len(ds))])
+    assert poses.dtype == np.float32 and poses.shape == gd["ds.pose.pose_gt"].shape
+    assert np.allclose(poses, gd["ds.pose.pose_gt"], rtol=0, atol=1e-6)
+    b = ds.batch_collator([ds[0], ds[1]])
+    assert isinstance(b["pose_gt"], torch.Tensor) and tuple(b["pose_gt"].shape) == (2, 4, 4)
+    first = [i for i in range(len(ds)) if ds.metadatas[ds.valid_inds[i]][3] == "0000000000"]
+    assert first and all(np.allclose(poses[i], np.eye(4), atol=1e-6) for i in first)       # the drive's first frame is the origin
