@@ -316,7 +316,10 @@ def main():
                 L.SCHEDULE_LOCKED = True
         for kv in args.opt:                     # A/B aid: --opt 6=128 -> sde_conv_set_option(SDE_OPT_WGRAD_BLOCKS, 128)
             k, v = kv.split("=")
-            HN.set_option(int(k), int(v))
+            if k == "bn_fuse":                  # --opt bn_fuse=2 -> sde_bn_set_fuse(2)
+                L.lib().sde_bn_set_fuse(int(v))
+            else:
+                HN.set_option(int(k), int(v))
         if args.no_side_stream:
             L.SIDE_STREAM = False
         if args.no_pgemm:

@@ -235,8 +235,8 @@ int sde_bn_apply(const void* y, const float* bnp, const void* residual, int relu
 /* sde_bn_finalize + sde_bn_apply in one launch (same arguments, count = M rows), for 16-bit types, C % 64 == 0 and at most 256 slab rows
  * (sde_bn_finalize_apply_ok): every workgroup reduces the slab columns of its own 64 channels, redundantly and in a fixed order. */
 int sde_bn_finalize_apply_ok(int tiles, int C, int dtype);
-/* sde_bn_bwd fuses its finalize and apply passes the same way when its partial slab is short; sde_bn_set_fuse(0) turns that off (A/B, tests).
- * Returns the previous value. */
+/* sde_bn_bwd fuses its finalize and apply passes the same way; for the big layers its reduce pass runs 1024-thread workgroups so that the partial
+ * slab stays within 256 rows.  sde_bn_set_fuse(0) turns the fusion off, (2) keeps it for the short slabs only (A/B, tests).  Returns the previous value. */
 int sde_bn_set_fuse(int on);
 int sde_bn_finalize_apply(const float* part, int tiles, int C, long count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                           float momentum, float eps, float* bnp, const void* y, const void* residual, int relu, int dtype, void* out, sde_stream_t stream);

@@ -46,4 +46,25 @@ print('busy per queue (ms/step):', {k: round(v / n / 1e6, 3) for k, v in q.items
 print(f'{"family":52s} {"total us":>9s} {"exclusive us":>12s}')
 for k, v in sorted(tot.items(), key=lambda kv: -excl[kv[0]])[:40]:
     print(f'{k:52s} {v/n/1e3:9.1f} {excl[k]/n/1e3:12.1f}')
+# phases of the LAST step: forward (up to the loss kernel: one queue, serial), backward (two queues: which one is the critical chain, how busy it
+# is and where it stalls), tail (after the last data-gradient kernel: stem weight gradient, slab sums, optimizer)
+last = rows[idx[-2] + 1: idx[-1] + 1]
+t0 = int(last[0]['Start_Timestamp'])
+S = lambda r: (int(r['Start_Timestamp']) - t0) / 1e3
+E = lambda r: (int(r['End_Timestamp']) - t0) / 1e3
+loss = next((i for i, r in enumerate(last) if 'silog_fwd' in r['Kernel_Name'] or 'photo_fwd' in r['Kernel_Name']), None)
+if loss is not None:
+    fw, bw = last[:loss], last[loss:]
+    print(f'forward: {len(fw)} kernels, {E(fw[-1]):.1f} us span, {sum(E(r) - S(r) for r in fw):.1f} us busy')
+    qs = collections.Counter(r['Queue_Id'] for r in bw)
+    for qid, _ in qs.most_common():
+        ch = [r for r in bw if r['Queue_Id'] == qid]
+        busy = sum(E(r) - S(r) for r in ch)
+        gaps = [(S(b_) - E(a_), fam(a_['Kernel_Name'])[:24], fam(b_['Kernel_Name'])[:24]) for a_, b_ in zip(ch, ch[1:]) if S(b_) - E(a_) > 3]
+        ftot = collections.Counter()
+        for r in ch: ftot[fam(r['Kernel_Name'])[:36]] += E(r) - S(r)
+        print(f'backward queue {qid}: {len(ch)} kernels, {S(ch[0]):.1f}..{E(ch[-1]):.1f} us, busy {busy:.1f} us, {len(gaps)} stalls > 3 us adding up to {sum(g[0] for g in gaps):.1f} us')
+        print('   largest: ' + ', '.join(f'{k} {v:.0f}' for k, v in ftot.most_common(8)))
+        for g in sorted(gaps, reverse=True)[:5]:
+            print(f'   stall {g[0]:6.1f} us  {g[1]} -> {g[2]}')
 PY

@@ -290,16 +290,27 @@ __global__ void __launch_bounds__(256) bn_finalize_apply_kernel(const float* __r
 // Combine per-thread column accumulators of a 256-thread block whose threads tid, tid+cch, tid+2cch, ... share a 16-byte
 // channel group (cch = groups per row, a divisor of 256).  sh: [256][NV] floats.  Thread t < cch returns the block sums of its
 // group in a[]; no float atomics (deterministic, and LDS float atomics are slow).
-template <int NV>
+template <int NV, int NT = 256>
 __device__ __forceinline__ void block_group_reduce(float (&a)[NV], int cch, float* sh) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int e = 0; e < NV; ++e) sh[e * 256 + t] = a[e];      // element-major: lanes hit consecutive banks
+    for (int e = 0; e < NV; ++e) sh[e * NT + t] = a[e];      // element-major: lanes hit consecutive banks
     __syncthreads();
+    if (NT > 256) {
+        // wide workgroups: the first 256 threads fold the other quarters onto themselves first (same column: NT and 256 are multiples of cch)
+        if (t < 256) {
+            for (int r = t + 256; r < NT; r += 256)
+#pragma unroll
+                for (int e = 0; e < NV; ++e) a[e] += sh[e * NT + r];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) sh[e * NT + t] = a[e];
+        }
+        __syncthreads();
+    }
     if (t < cch) {
         for (int r = t + cch; r < 256; r += cch)
 #pragma unroll
-            for (int e = 0; e < NV; ++e) a[e] += sh[e * 256 + r];
+            for (int e = 0; e < NV; ++e) a[e] += sh[e * NT + r];
     }
 }
 
@@ -345,15 +356,17 @@ __device__ __forceinline__ void bn_load_dz(const T* d0, const T* d1, const T* d2
     }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ dout1, const T* __restrict__ dout2,
-                                                            const T* __restrict__ out, const T* __restrict__ y,
-                                                            const float* __restrict__ bnp, int relu, long M, int C, long rows_per_block,
-                                                            float* __restrict__ part, T* __restrict__ gm) {
+// NT = 1024 (16-bit types, host-checked fast-path shapes only): the same threads in flight from a quarter of the workgroups, so that the partial
+// slab of the big layers stays within the 256 rows the fused finalize + apply launch re-reduces per workgroup.
+template <typename T, int NT = 256>
+__global__ void __launch_bounds__(NT) bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ dout1, const T* __restrict__ dout2,
+                                                           const T* __restrict__ out, const T* __restrict__ y,
+                                                           const float* __restrict__ bnp, int relu, long M, int C, long rows_per_block,
+                                                           float* __restrict__ part, T* __restrict__ gm) {
     constexpr int V = VecOf<T>::V;
-    extern __shared__ float sh[];   // fast path: [256][2V]; fallback: [2][C]
+    extern __shared__ float sh[];   // fast path: [NT][2V]; fallback: [2][C]
     const int cch = C / V;
-    if (cch <= 256 && 256 % cch == 0) {
+    if (NT > 256 || (cch <= 256 && 256 % cch == 0)) {
         const int col = threadIdx.x % cch, c0 = col * V;
         float mean[V], rstd[V], sc[V], sf[V], acc[2 * V];
 #pragma unroll
@@ -362,7 +375,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
             acc[e] = 0.f; acc[V + e] = 0.f;
         }
         const long total = M * cch;
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
             float d[V], yv[V];
             load_vec<T>(y + i * V, yv);
             bn_load_dz<T, V>(dout, dout1, dout2, out, relu, i * V, d, yv, sc, sf);
@@ -373,7 +386,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
             for (int e = 0; e < V; ++e) { acc[e] += d[e]; acc[V + e] += d[e] * ((yv[e] - mean[e]) * rstd[e]); }
         }
-        block_group_reduce<2 * V>(acc, cch, sh);
+        block_group_reduce<2 * V, NT>(acc, cch, sh);
         if (threadIdx.x < cch) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -1186,7 +1199,13 @@ int sde_bn_finalize(const float* part, int tiles, int C, long count, const float
 }
 
 static int g_bn_fuse = 1;       // sde_bn_set_fuse(0): always the separate finalize and apply launches (A/B, tests)
-int sde_bn_set_fuse(int on) { const int old = g_bn_fuse; g_bn_fuse = on ? 1 : 0; return old; }
+static int g_bn_wide = 1;       // sde_bn_set_fuse(2): fused for short slabs only, the big layers keep 256-thread reduce workgroups + three launches (A/B)
+int sde_bn_set_fuse(int on) {
+    const int old = g_bn_fuse ? (g_bn_wide ? 1 : 2) : 0;
+    g_bn_fuse = on ? 1 : 0;
+    g_bn_wide = on == 1;
+    return old;
+}
 
 int sde_bn_finalize_apply_ok(int tiles, int C, int dtype) { return SDE_IS16(dtype) && C % 64 == 0 && tiles >= 1 && tiles <= BNFA_MAX_ROWS; }
 
@@ -1254,9 +1273,21 @@ int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const voi
     SDE_CHECK_ARG(dout1 || !dout2, "sde_bn_bwd: dout2 without dout1");
     (void)gamma;
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = sde_reduce_num_blocks(M, C);
+    int nblk = sde_reduce_num_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
     const size_t lds = (2 * (size_t)C > 256 * 16 ? 2 * (size_t)C : 256 * 16) * sizeof(float);
+    const int cch = C / V;
+    const bool wide = g_bn_fuse && g_bn_wide && SDE_IS16(dtype) && C % 64 == 0 && nblk > BNFA_MAX_ROWS && cch <= 256 && 256 % cch == 0;
+    if (wide) {
+        // big layers: 1024-thread workgroups, a quarter as many of them -> at most 256 partial rows, and finalize + apply become one launch below
+        nblk = (nblk + 3) / 4;
+        if (dtype == SDE_BF16)
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 1024>), dim3(nblk), dim3(1024), 1024 * 16 * sizeof(float), s, (const bf16_t*)dout, (const bf16_t*)dout1,
+                               (const bf16_t*)dout2, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part, (bf16_t*)gm);
+        else
+            hipLaunchKernelGGL((bn_bwd_reduce_kernel<half_t, 1024>), dim3(nblk), dim3(1024), 1024 * 16 * sizeof(float), s, (const half_t*)dout, (const half_t*)dout1,
+                               (const half_t*)dout2, (const half_t*)out, (const half_t*)y, bnp, relu, M, C, rpb, part, (half_t*)gm);
+    } else
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)dout1, (const float*)dout2, (const float*)out, (const float*)y, bnp, relu, M, C, rpb, part, (float*)gm),
                hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)dout1, (const bf16_t*)dout2, (const bf16_t*)out, (const bf16_t*)y, bnp, relu, M, C, rpb, part, (bf16_t*)gm),
