@@ -115,6 +115,15 @@ int sde_silog_fwd(const float* est, const float* gt, int B, int h, int w, int H,
                   sde_stream_t stream);
 int sde_silog_bwd(const float* est, const float* gt, const float* stats, const float* gout, float gscale, float variance_focus, int B, int h,
                   int w, int H, int W, float* d_est, int accumulate, sde_stream_t stream);
+/* The same loss summed over up to SDE_SILOG_MAX_SCALES prediction scales against ONE ground truth (Supervised.py:L42-47: the four decoder scales,
+ * weight 1/4 each) in one launch per phase: total[0] = sum_k weight[k] * SILog(est[k], nearest(gt)), stats [n][4] as above per scale (bit-identical to
+ * the single-scale call), part: [sde_silog_multi_num_blocks][3].  Backward writes d_est[k] = gout * gscale * weight[k] * dSILog_k/d est[k]. */
+#define SDE_SILOG_MAX_SCALES 4
+int sde_silog_multi_num_blocks(int B, const int* h, const int* w, int n);
+int sde_silog_multi_fwd(const float* const* est, const float* gt, int B, const int* h, const int* w, const float* weight, int n, int H, int W,
+                        float variance_focus, float* part, float* stats, float* total, sde_stream_t stream);
+int sde_silog_multi_bwd(const float* const* est, const float* gt, const float* stats, const float* gout, float gscale, float variance_focus, int B,
+                        const int* h, const int* w, const float* weight, int n, int H, int W, float* const* d_est, sde_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Convolution engine (NHWC activations, fp32 or bf16 storage, fp32 accumulate)
@@ -254,11 +263,16 @@ int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const voi
 /* nn.MaxPool2d(3, 2, 1) (resnet_encoder.py:L94).  idx: [B,OH,OW,C] u8 arg-max saved for backward. */
 int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* out, uint8_t* idx, sde_stream_t stream);
 int sde_maxpool_bwd(const void* dout, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream);
+/* ... with the gradients of two consumers of the pooled tensor summed on the fly (dout1 may be NULL) */
+int sde_maxpool_bwd_sum(const void* dout, const void* dout1, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream);
 
 /* dz = dout * act'(out) (nn.ELU / nn.ReLU backward) fused with the bias gradient dbias[c] (+)= sum_rows dz[:, c], c < Cbias.
  * dz and/or dbias may be NULL; part: [sde_reduce_num_blocks(M, C) + SDE_REDUCE_ROWS][C] workspace (needed when dbias != NULL). */
 int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias, int accumulate,
                      sde_stream_t stream);
+/* ... of an activation with two consumers (a decoder level feeds its disparity head and the next level): dz = act'(out) * (dout + dout1), dout1 may be NULL */
+int sde_act_bwd_bias_sum(const void* dout, const void* dout1, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias,
+                         int accumulate, sde_stream_t stream);
 
 /* Backward of ReflectionPad2d(1) [+ nearest x2 upsample + channel concat] (depth_decoder.py:L40-47,L102-105):
  * dxp [B,H+2,W+2,C] (gradient w.r.t. the padded virtual input, from the data-gradient GEMM) ->

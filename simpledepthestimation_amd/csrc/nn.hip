@@ -565,8 +565,8 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx, int B, int H, int W, int C, int OH,
-                                                          int OW, T* __restrict__ dx) {
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ dout1, const uint8_t* __restrict__ idx, int B, int H,
+                                                          int W, int C, int OH, int OW, T* __restrict__ dx) {
     constexpr int V = VecOf<T>::V;
     const int cch = C / V;
     const long total = (long)B * H * W * cch;
@@ -593,6 +593,12 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
                 const long o = ((((long)b * OH + oh) * OW + ow) * cch + col) * V;
                 float d[V];
                 load_vec<T>(dout + o, d);
+                if (dout1) {          // the pooled tensor had two consumers: their gradients are summed here
+                    float t[V];
+                    load_vec<T>(dout1 + o, t);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) d[e] += t[e];
+                }
                 const uint8_t* ip = idx + o;
 #pragma unroll
                 for (int e = 0; e < V; ++e)
@@ -607,8 +613,8 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
 // Activation backward fused with the bias-gradient column sums: dz = dout * act'(out); partial[blk][C] = sum_rows dz
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__ dout, const T* __restrict__ out, int act, long M, int C,
-                                                           long rows_per_block, T* __restrict__ dz, float* __restrict__ part) {
+__global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__ dout, const T* __restrict__ dout1, const T* __restrict__ out, int act, long M,
+                                                           int C, long rows_per_block, T* __restrict__ dz, float* __restrict__ part) {
     constexpr int V = VecOf<T>::V;
     extern __shared__ float sh[];   // fast path: [256][V]; fallback: [C]
     const int cch = C / V;
@@ -621,6 +627,11 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
             float d[V], o[V];
             load_vec<T>(dout + i * V, d);
+            if (dout1) {              // second consumer of the activation (decoder level -> its disparity head and the next level)
+                load_vec<T>(dout1 + i * V, o);
+#pragma unroll
+                for (int e = 0; e < V; ++e) d[e] += o[e];
+            }
             if (act != SDE_ACT_NONE) {
                 load_vec<T>(out + i * V, o);
 #pragma unroll
@@ -652,6 +663,11 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__
         const long off = (r0 * cch + i) * V;
         float d[V], o[V];
         load_vec<T>(dout + off, d);
+        if (dout1) {
+            load_vec<T>(dout1 + off, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) d[e] += o[e];
+        }
         if (act != SDE_ACT_NONE) {
             load_vec<T>(out + off, o);
 #pragma unroll
@@ -1337,20 +1353,29 @@ int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* 
 }
 
 int sde_maxpool_bwd(const void* dout, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream) {
+    return sde_maxpool_bwd_sum(dout, nullptr, idx, B, H, W, C, dtype, dx, stream);
+}
+
+int sde_maxpool_bwd_sum(const void* dout, const void* dout1, const uint8_t* idx, int B, int H, int W, int C, int dtype, void* dx, sde_stream_t stream) {
     const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(dout && idx && dx && B > 0 && H > 1 && W > 1 && C % V == 0, "sde_maxpool_bwd: bad argument");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
     const int nb = grid_for((long)B * H * W * (C / V));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, idx, B, H, W, C, OH, OW, (float*)dx),
-               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, idx, B, H, W, C, OH, OW, (bf16_t*)dx),
-               hipLaunchKernelGGL(maxpool_bwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dout, idx, B, H, W, C, OH, OW, (half_t*)dx));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)dout1, idx, B, H, W, C, OH, OW, (float*)dx),
+               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)dout1, idx, B, H, W, C, OH, OW, (bf16_t*)dx),
+               hipLaunchKernelGGL(maxpool_bwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dout, (const half_t*)dout1, idx, B, H, W, C, OH, OW, (half_t*)dx));
     SDE_CHECK_LAUNCH("sde_maxpool_bwd");
     return SDE_OK;
 }
 
 int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias, int accumulate,
                      sde_stream_t stream) {
+    return sde_act_bwd_bias_sum(dout, nullptr, out, act, M, C, dtype, dz, part, dbias, Cbias, accumulate, stream);
+}
+
+int sde_act_bwd_bias_sum(const void* dout, const void* dout1, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias,
+                         int accumulate, sde_stream_t stream) {
     const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(dout && M > 0 && C > 0 && C % V == 0, "sde_act_bwd_bias: bad argument");
     SDE_CHECK_ARG(act == SDE_ACT_NONE || out, "sde_act_bwd_bias: activation backward needs the saved output");
@@ -1361,9 +1386,9 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
     float* p = dbias ? part : nullptr;
     const size_t lds = ((size_t)C > 256 * 8 ? (size_t)C : 256 * 8) * sizeof(float);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(act_bwd_bias_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)out, act, M, C, rpb, (float*)dz, p),
-               hipLaunchKernelGGL(act_bwd_bias_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, act, M, C, rpb, (bf16_t*)dz, p),
-               hipLaunchKernelGGL(act_bwd_bias_kernel<half_t>, dim3(nblk), dim3(256), lds, s, (const half_t*)dout, (const half_t*)out, act, M, C, rpb, (half_t*)dz, p));
+               hipLaunchKernelGGL(act_bwd_bias_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)dout1, (const float*)out, act, M, C, rpb, (float*)dz, p),
+               hipLaunchKernelGGL(act_bwd_bias_kernel<bf16_t>, dim3(nblk), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)dout1, (const bf16_t*)out, act, M, C, rpb, (bf16_t*)dz, p),
+               hipLaunchKernelGGL(act_bwd_bias_kernel<half_t>, dim3(nblk), dim3(256), lds, s, (const half_t*)dout, (const half_t*)dout1, (const half_t*)out, act, M, C, rpb, (half_t*)dz, p));
     SDE_CHECK_LAUNCH("sde_act_bwd_bias");
     if (dbias) {
         int rows = nblk;

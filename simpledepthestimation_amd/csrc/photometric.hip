@@ -808,6 +808,106 @@ __global__ void __launch_bounds__(256) silog_bwd_kernel(const float* __restrict_
     }
 }
 
+// The multi-scale form of the three kernels above (Supervised.py:L42-47 sums the loss of the four prediction scales against one ground truth):
+// every scale keeps the block partition and the summation order of the single-scale launch (bit-identical per-scale statistics), the launches are
+// one per phase instead of one per scale, and the finalize also forms sum_k weight[k] * loss[k].
+struct SilogScales {
+    const float* est[SDE_SILOG_MAX_SCALES];
+    float* d_est[SDE_SILOG_MAX_SCALES];
+    int h[SDE_SILOG_MAX_SCALES], w[SDE_SILOG_MAX_SCALES], blk_end[SDE_SILOG_MAX_SCALES];
+    float sh[SDE_SILOG_MAX_SCALES], sw[SDE_SILOG_MAX_SCALES], weight[SDE_SILOG_MAX_SCALES];
+    int n;
+};
+
+__device__ __forceinline__ int silog_scale_of(const SilogScales& a, int blk, int& first, int& count) {
+    int k = 0;
+    while (k + 1 < a.n && blk >= a.blk_end[k]) ++k;
+    first = k ? a.blk_end[k - 1] : 0;
+    count = a.blk_end[k] - first;
+    return k;
+}
+
+__global__ void __launch_bounds__(256) silog_multi_fwd_kernel(SilogScales a, const float* __restrict__ gt, int B, int H, int W, float* __restrict__ part) {
+    __shared__ float red[16];
+    int first, count;
+    const int k = silog_scale_of(a, blockIdx.x, first, count);
+    const int h = a.h[k], w = a.w[k];
+    const float* __restrict__ est = a.est[k];
+    const float sh_ = a.sh[k], sw_ = a.sw[k];
+    const long n = (long)B * h * w;
+    float c = 0.f, s1 = 0.f, s2 = 0.f;
+    for (long i = (long)(blockIdx.x - first) * 256 + threadIdx.x; i < n; i += (long)count * 256) {
+        const int x = (int)(i % w), y = (int)((i / w) % h), b = (int)(i / ((long)w * h));
+        const int ys = min((int)floorf((float)y * sh_), H - 1), xs = min((int)floorf((float)x * sw_), W - 1);
+        const float g = gt[((long)b * H + ys) * W + xs];
+        if (g > 1.0f) {
+            const float d = logf(est[i]) - logf(g);
+            c += 1.f; s1 += d; s2 += d * d;
+        }
+    }
+    c = sde_block_sum(c, red);
+    if (threadIdx.x == 0) part[blockIdx.x * 3 + 0] = c;
+    s1 = sde_block_sum(s1, red);
+    if (threadIdx.x == 0) part[blockIdx.x * 3 + 1] = s1;
+    s2 = sde_block_sum(s2, red);
+    if (threadIdx.x == 0) part[blockIdx.x * 3 + 2] = s2;
+}
+
+// stats[k][0..3] as silog_finalize_kernel; total[0] = sum_k weight[k] * loss[k] (scales in order, fp32)
+__global__ void silog_multi_finalize_kernel(const float* __restrict__ part, SilogScales a, float vf, float* __restrict__ stats, float* __restrict__ total) {
+    __shared__ double sh[3][64];
+    __shared__ float loss[SDE_SILOG_MAX_SCALES];
+    const int t = threadIdx.x;
+    for (int k = 0; k < a.n; ++k) {
+        const int first = k ? a.blk_end[k - 1] : 0, nblk = a.blk_end[k] - first;
+        const float* p = part + (long)first * 3;
+        double c = 0, s1 = 0, s2 = 0;
+        for (int i = t; i < nblk; i += 64) { c += p[i * 3]; s1 += p[i * 3 + 1]; s2 += p[i * 3 + 2]; }
+        __syncthreads();
+        sh[0][t] = c; sh[1][t] = s1; sh[2][t] = s2;
+        __syncthreads();
+        if (t == 0) {
+            c = s1 = s2 = 0;
+            for (int i = 0; i < 64; ++i) { c += sh[0][i]; s1 += sh[1][i]; s2 += sh[2][i]; }
+            const double m1 = s1 / c, m2 = s2 / c;
+            stats[4 * k + 0] = (float)c; stats[4 * k + 1] = (float)m1; stats[4 * k + 2] = (float)m2;
+            loss[k] = (float)(sqrt(m2 - (double)vf * m1 * m1) * 10.0);
+            stats[4 * k + 3] = loss[k];
+        }
+    }
+    if (t == 0) {
+        float s = 0.f;
+        for (int k = 0; k < a.n; ++k) s += a.weight[k] * loss[k];
+        total[0] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) silog_multi_bwd_kernel(SilogScales a, const float* __restrict__ gt, const float* __restrict__ stats,
+                                                              const float* __restrict__ gout, float gscale, float vf, int B, int H, int W) {
+    int first, count;
+    const int k = silog_scale_of(a, blockIdx.x, first, count);
+    const int h = a.h[k], w = a.w[k];
+    const float* __restrict__ est = a.est[k];
+    float* __restrict__ d_est = a.d_est[k];
+    const float sh_ = a.sh[k], sw_ = a.sw[k];
+    const long n = (long)B * h * w;
+    const float cnt = stats[4 * k], m1 = stats[4 * k + 1], loss = stats[4 * k + 3];
+    const float g = gout[0] * gscale * a.weight[k];
+    const float kk = (loss > 0.f) ? 100.0f / (loss * cnt) : 0.f;
+    for (long i = (long)(blockIdx.x - first) * 256 + threadIdx.x; i < n; i += (long)count * 256) {
+        const int x = (int)(i % w), y = (int)((i / w) % h), b = (int)(i / ((long)w * h));
+        const int ys = min((int)floorf((float)y * sh_), H - 1), xs = min((int)floorf((float)x * sw_), W - 1);
+        const float gv = gt[((long)b * H + ys) * W + xs];
+        float r = 0.f;
+        if (gv > 1.0f) {
+            const float e = est[i];
+            const float d = logf(e) - logf(gv);
+            r = g * kk * (d - vf * m1) / e;
+        }
+        d_est[i] = r;
+    }
+}
+
 // pose_vec2mat (pose_utils.py:L98-137): R = X(rx) Y(ry) Z(rz), T = [R t; 0 0 0 1]; also its VJP
 __global__ void pose_vec2mat_kernel(const float* __restrict__ vec, float* __restrict__ mat, int n) {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -1039,6 +1139,52 @@ int sde_silog_bwd(const float* est, const float* gt, const float* stats, const f
     hipLaunchKernelGGL(silog_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, est, gt, stats, gout, gscale, variance_focus, B, h, w, H,
                        W, sh, sw, d_est, accumulate);
     SDE_CHECK_LAUNCH("sde_silog_bwd");
+    return SDE_OK;
+}
+
+static int silog_scales(const float* const* est, float* const* d_est, const int* h, const int* w, const float* weight, int n, int B, int H, int W,
+                        SilogScales& a) {
+    SDE_CHECK_ARG(est && h && w && weight && n >= 1 && n <= SDE_SILOG_MAX_SCALES && B > 0, "sde_silog_multi: bad scale table (n=%d)", n);
+    a.n = n;
+    int end = 0;
+    for (int k = 0; k < n; ++k) {
+        SDE_CHECK_ARG(est[k] && h[k] > 0 && w[k] > 0 && H >= h[k] && W >= w[k] && (!d_est || d_est[k]), "sde_silog_multi: bad scale %d", k);
+        a.est[k] = est[k]; a.d_est[k] = d_est ? d_est[k] : nullptr; a.h[k] = h[k]; a.w[k] = w[k]; a.weight[k] = weight[k];
+        a.sh[k] = (float)((double)H / (double)h[k]); a.sw[k] = (float)((double)W / (double)w[k]);
+        end += sde_silog_num_blocks(B, h[k], w[k]);
+        a.blk_end[k] = end;
+    }
+    return SDE_OK;
+}
+
+int sde_silog_multi_num_blocks(int B, const int* h, const int* w, int n) {
+    int end = 0;
+    for (int k = 0; k < n; ++k) end += sde_silog_num_blocks(B, h[k], w[k]);
+    return end;
+}
+
+int sde_silog_multi_fwd(const float* const* est, const float* gt, int B, const int* h, const int* w, const float* weight, int n, int H, int W,
+                        float variance_focus, float* part, float* stats, float* total, sde_stream_t stream) {
+    SDE_CHECK_ARG(gt && part && stats && total, "sde_silog_multi_fwd: null pointer");
+    SilogScales a;
+    const int rc = silog_scales(est, nullptr, h, w, weight, n, B, H, W, a);
+    if (rc != SDE_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(silog_multi_fwd_kernel, dim3(a.blk_end[n - 1]), dim3(256), 0, s, a, gt, B, H, W, part);
+    SDE_CHECK_LAUNCH("sde_silog_multi_fwd");
+    hipLaunchKernelGGL(silog_multi_finalize_kernel, dim3(1), dim3(64), 0, s, part, a, variance_focus, stats, total);
+    SDE_CHECK_LAUNCH("sde_silog_multi_fwd/finalize");
+    return SDE_OK;
+}
+
+int sde_silog_multi_bwd(const float* const* est, const float* gt, const float* stats, const float* gout, float gscale, float variance_focus, int B,
+                        const int* h, const int* w, const float* weight, int n, int H, int W, float* const* d_est, sde_stream_t stream) {
+    SDE_CHECK_ARG(gt && stats && gout && d_est, "sde_silog_multi_bwd: null pointer");
+    SilogScales a;
+    const int rc = silog_scales(est, d_est, h, w, weight, n, B, H, W, a);
+    if (rc != SDE_OK) return rc;
+    hipLaunchKernelGGL(silog_multi_bwd_kernel, dim3(a.blk_end[n - 1]), dim3(256), 0, (hipStream_t)stream, a, gt, stats, gout, gscale, variance_focus, B, H, W);
+    SDE_CHECK_LAUNCH("sde_silog_multi_bwd");
     return SDE_OK;
 }
 

@@ -42,6 +42,9 @@ _PROTOS = {
     "sde_silog_num_blocks": ([_I, _I, _I], c_int),
     "sde_silog_fwd": ([_P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P], c_int),
     "sde_silog_bwd": ([_P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P, _I, _P], c_int),
+    "sde_silog_multi_num_blocks": ([_I, _P, _P, _I], c_int),
+    "sde_silog_multi_fwd": ([_P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P], c_int),
+    "sde_silog_multi_bwd": ([_P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _I, _I, _I, _P, _P], c_int),
 }
 
 _lib = None

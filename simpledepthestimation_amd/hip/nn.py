@@ -49,7 +49,9 @@ L.register_protos({
     "sde_bn_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _LG, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P], c_int),
     "sde_maxpool_fwd": ([_P, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
     "sde_maxpool_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
+    "sde_maxpool_bwd_sum": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_act_bwd_bias": ([_P, _P, _I, _LG, _I, _I, _P, _P, _P, _I, _I, _P], c_int),
+    "sde_act_bwd_bias_sum": ([_P, _P, _P, _I, _LG, _I, _I, _P, _P, _P, _I, _I, _P], c_int),
     "sde_refl_fold": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
     "sde_depth_head_fwd": ([_P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P], c_int),
     "sde_depth_head_bwd": ([_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P], c_int),
@@ -171,8 +173,10 @@ def conv_raw(d, x_dtype, w_packed, bias, act, Cout, ldy, want_stats, device, kin
 # ---------------------------------------------------------------------------------------------------------------
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, stride, pad, reflect, act, upcat, want_stats, owner=None):
+    def forward(ctx, x0, x1, weight, bias, stride, pad, reflect, act, upcat, want_stats, owner=None, n_out=1):
         ctx.set_materialize_grads(False)      # the statistics output never carries a gradient: do not launch zero fills for it
+        if n_out > 1 and want_stats:
+            raise L.SdeHipError("conv2d: output aliases (n_out) belong to the BatchNorm that follows when statistics are requested")
         if not x0.is_contiguous() or (x1 is not None and not x1.is_contiguous()):
             raise L.SdeHipError("conv2d: NHWC inputs must be contiguous")
         dt = x0.dtype
@@ -202,14 +206,24 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x0, x1, weight, y if act != ACT_NONE else None)
         ctx.params = (weight, bias)
         ctx.cfg = (stride, pad, reflect, act, upcat, bias is not None, IH, IW, OH, OW)
+        ctx.want_stats = want_stats
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
+        if n_out > 1:       # one alias per consumer: backward receives their gradients separately and sde_act_bwd_bias_sum adds them on the fly
+            return (y,) + tuple(y.view(y.shape) for _ in range(n_out - 1))
         return y
 
     @staticmethod
-    def backward(ctx, dy, dstats=None):
+    def backward(ctx, *douts):
         x0, x1, weight, y = ctx.saved_tensors
+        grads = [douts[0]] if ctx.want_stats else [g for g in douts if g is not None]
+        dy = grads[0] if grads else None
+        dy1 = None
+        if len(grads) > 1:
+            dy1 = grads[1].contiguous()
+            for g in grads[2:]:
+                dy1 = dy1 + g
         stride, pad, reflect, act, upcat, has_bias, IH, IW, OH, OW = ctx.cfg
         dt = x0.dtype
         V = vec_of(dt)
@@ -220,7 +234,7 @@ class _Conv2d(torch.autograd.Function):
         Cout, Cin, KH, KW = weight.shape
         ldy = pad_to(Cout, V)
         if dy is None:
-            return (None,) * 11
+            return (None,) * 12
         if MAIN_STREAM is not None and torch.cuda.current_stream() != MAIN_STREAM:
             # e.g. part of the forward pass ran under torch.cuda.stream(helper): autograd then replays this node's backward on that stream,
             # underneath fork / join events recorded against the trainer's stream (operands could be recycled while a GEMM still reads them)
@@ -232,14 +246,14 @@ class _Conv2d(torch.autograd.Function):
         # 1. activation backward + bias gradient
         dbias = None
         dz = dy
-        if act != ACT_NONE or has_bias:
+        if act != ACT_NONE or has_bias or dy1 is not None:
             nblk = lib.sde_reduce_num_blocks(M, ldy)
             part = torch.empty(nblk + REDUCE_ROWS, ldy, device=dev) if has_bias else None
             bslot = _grad_slot(ctx.params[1]) if has_bias else None
             dbias = (bslot if bslot is not None else torch.empty(Cout, device=dev)) if has_bias else None
-            dz = torch.empty_like(dy) if act != ACT_NONE else None
-            L.check(lib.sde_act_bwd_bias(L.ptr(dy), L.ptr(y), act, M, ldy, dtype_code(dt), L.ptr(dz), L.ptr(part), L.ptr(dbias), Cout,
-                                         int(bslot is not None), L.stream()), "sde_act_bwd_bias")
+            dz = torch.empty_like(dy) if (act != ACT_NONE or dy1 is not None) else None
+            L.check(lib.sde_act_bwd_bias_sum(L.ptr(dy), L.ptr(dy1), L.ptr(y), act, M, ldy, dtype_code(dt), L.ptr(dz), L.ptr(part), L.ptr(dbias), Cout,
+                                             int(bslot is not None), L.stream()), "sde_act_bwd_bias_sum")
             if bslot is not None:
                 dbias = None
             if dz is None:
@@ -380,7 +394,7 @@ class _Conv2d(torch.autograd.Function):
                 WGRAD_DEFER.pending.append((ev, (dz, x0, x1)))
             else:
                 torch.cuda.current_stream().wait_stream(side)       # join: dz / x0 / x1 stay alive until both GEMMs are done
-        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None
+        return dx0, dx1, dw, dbias, None, None, None, None, None, None, None, None
 
 
 def _wptr(t):
@@ -527,13 +541,15 @@ class WeightPacker:
         """Kept for the trainer's call order (the data-gradient operands are packed by the same launch as the forward ones)."""
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, skip=None, upsample=False, bn_stats=False, owner=None):
+def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, act=ACT_NONE, skip=None, upsample=False, bn_stats=False, owner=None, n_out=1):
     """y = act(conv(x) + bias) on NHWC tensors.
 
     upsample=True: the input is cat(nearest_x2(x), skip) (skip may be None) -- depth_decoder.py:L102-105 -- gathered on the fly.
     bn_stats=True additionally returns the per-tile (sum, sum^2) slab BatchNorm needs.
+    n_out > 1 returns that many aliases of the output, one per consumer: their gradients are summed by the activation-backward kernel instead
+    of by an autograd add kernel per extra consumer.
     """
-    return _Conv2d.apply(x, skip, weight, bias, int(stride), int(pad), bool(reflect), int(act), bool(upsample), bool(bn_stats), owner)
+    return _Conv2d.apply(x, skip, weight, bias, int(stride), int(pad), bool(reflect), int(act), bool(upsample), bool(bn_stats), owner, int(n_out))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -623,7 +639,8 @@ def batch_norm_act(y, stats, gamma, beta, running_mean, running_var, residual=No
 # ---------------------------------------------------------------------------------------------------------------
 class _MaxPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, n_out=1):
+        ctx.set_materialize_grads(False)
         B, H, W, C = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         out = torch.empty(B, OH, OW, C, device=x.device, dtype=x.dtype)
@@ -631,19 +648,30 @@ class _MaxPool(torch.autograd.Function):
         L.check(L.lib().sde_maxpool_fwd(L.ptr(x.contiguous()), B, H, W, C, dtype_code(x.dtype), L.ptr(out), L.ptr(idx), L.stream()), "sde_maxpool_fwd")
         ctx.save_for_backward(idx)
         ctx.shape = (B, H, W, C)
+        if n_out > 1:
+            return (out,) + tuple(out.view(out.shape) for _ in range(n_out - 1))
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, *douts):
         (idx,) = ctx.saved_tensors
         B, H, W, C = ctx.shape
-        dx = torch.empty(B, H, W, C, device=dout.device, dtype=dout.dtype)
-        L.check(L.lib().sde_maxpool_bwd(L.ptr(dout.contiguous()), L.ptr(idx), B, H, W, C, dtype_code(dout.dtype), L.ptr(dx), L.stream()), "sde_maxpool_bwd")
-        return dx
+        grads = [g.contiguous() for g in douts if g is not None]
+        if not grads:
+            return None, None
+        d0, d1 = grads[0], None
+        if len(grads) > 1:
+            d1 = grads[1]
+            for g in grads[2:]:
+                d1 = d1 + g
+        dx = torch.empty(B, H, W, C, device=d0.device, dtype=d0.dtype)
+        L.check(L.lib().sde_maxpool_bwd_sum(L.ptr(d0), L.ptr(d1), L.ptr(idx), B, H, W, C, dtype_code(d0.dtype), L.ptr(dx), L.stream()), "sde_maxpool_bwd_sum")
+        return dx, None
 
 
-def max_pool_3x3_s2(x):
-    return _MaxPool.apply(x)
+def max_pool_3x3_s2(x, n_out=1):
+    """n_out > 1: that many aliases of the pooled tensor (layer1's first block reads it twice); backward sums their gradients in the kernel."""
+    return _MaxPool.apply(x, int(n_out))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -253,6 +253,57 @@ class _Silog(torch.autograd.Function):
         return d_est, None, None
 
 
+class _SilogMulti(torch.autograd.Function):
+    """sum_k weights[k] * SILog(ests[k], nearest(gt)) over the prediction scales: one forward launch + one finalize, one backward launch."""
+
+    @staticmethod
+    def forward(ctx, gt, vf, weights, *ests):
+        import ctypes
+        ests = [_f32c(e) for e in ests]
+        gt = _f32c(gt)
+        n, B = len(ests), ests[0].shape[0]
+        H, W = gt.shape[-2:]
+        dev = gt.device
+        lib = L.lib()
+        hs = (ctypes.c_int * n)(*[e.shape[-2] for e in ests])
+        ws = (ctypes.c_int * n)(*[e.shape[-1] for e in ests])
+        wt = (ctypes.c_float * n)(*[float(x) for x in weights])
+        ep = (ctypes.c_void_p * n)(*[e.data_ptr() for e in ests])
+        part = torch.empty(lib.sde_silog_multi_num_blocks(B, hs, ws, n) * 3, device=dev)
+        stats = torch.empty(n, 4, device=dev)
+        total = torch.empty((), device=dev)
+        L.check(lib.sde_silog_multi_fwd(ep, L.ptr(gt), B, hs, ws, wt, n, H, W, vf, L.ptr(part), L.ptr(stats), L.ptr(total), L.stream()), "sde_silog_multi_fwd")
+        ctx.save_for_backward(gt, stats, *ests)
+        ctx.cfg = (vf, tuple(float(x) for x in weights))
+        return total
+
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes
+        gt, stats, *ests = ctx.saved_tensors
+        vf, weights = ctx.cfg
+        n, B = len(ests), ests[0].shape[0]
+        H, W = gt.shape[-2:]
+        d = [torch.empty_like(e) for e in ests]
+        hs = (ctypes.c_int * n)(*[e.shape[-2] for e in ests])
+        ws = (ctypes.c_int * n)(*[e.shape[-1] for e in ests])
+        wt = (ctypes.c_float * n)(*weights)
+        ep = (ctypes.c_void_p * n)(*[e.data_ptr() for e in ests])
+        dp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in d])
+        L.check(L.lib().sde_silog_multi_bwd(ep, L.ptr(gt), L.ptr(stats), L.ptr(_f32c(gout)), 1.0, vf, B, hs, ws, wt, n, H, W, dp, L.stream()), "sde_silog_multi_bwd")
+        return (None, None, None) + tuple(d)
+
+
+MAX_SILOG_SCALES = 4
+
+
+def silog_loss_multi(depth_ests, depth_gt_full, variance_focus, weights):
+    """sum_k weights[k] * silog_loss(depth_ests[k], depth_gt_full) (Supervised.py:L42-47) in one launch per phase."""
+    if not 1 <= len(depth_ests) <= MAX_SILOG_SCALES or len(weights) != len(depth_ests):
+        raise L.SdeHipError(f"silog_loss_multi: 1..{MAX_SILOG_SCALES} scales with one weight each, got {len(depth_ests)} / {len(weights)}")
+    return _SilogMulti.apply(depth_gt_full, float(variance_focus), tuple(weights), *depth_ests)
+
+
 def silog_loss(depth_est, depth_gt_full, variance_focus=0.85):
     """losses.py:L10-13 applied to (pred, resize_img(gt, pred.shape, 'nearest')) -- Supervised.py:L44-45 -- in one kernel."""
     return _Silog.apply(depth_est, depth_gt_full, float(variance_focus))

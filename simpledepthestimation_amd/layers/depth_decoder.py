@@ -5,6 +5,7 @@ coarsest (4) to the finest (0), then the four disparity heads; ELU convolutions 
 heads at ``decoder.K.conv.*``.  What the reference does as separate modules -- reflection padding, the nearest x2 up-sampling, the skip
 concatenation, the ELU -- is folded into the convolution's loader / epilogue here, so a level is two kernel launches.
 """
+import torch
 from torch import nn
 
 from ..hip import nn as HN
@@ -28,8 +29,8 @@ class Conv3x3(nn.Module):
         nn.Module.__init__(self)
         self.conv = HipConv2d(int(in_channels), int(out_channels), 3, 1, 1, bias=True, reflect=use_refl)
 
-    def forward(self, x, skip=None, upsample=False, act=HN.ACT_NONE):
-        return self.conv(x, skip=skip, upsample=upsample, act=act)
+    def forward(self, x, skip=None, upsample=False, act=HN.ACT_NONE, n_out=1):
+        return self.conv(x, skip=skip, upsample=upsample, act=act, n_out=n_out)
 
 
 class ConvBlock(nn.Module):
@@ -39,8 +40,8 @@ class ConvBlock(nn.Module):
         nn.Module.__init__(self)
         self.conv = Conv3x3(in_channels, out_channels)
 
-    def forward(self, x, skip=None, upsample=False):
-        return self.conv(x, skip=skip, upsample=upsample, act=HN.ACT_ELU)
+    def forward(self, x, skip=None, upsample=False, n_out=1):
+        return self.conv(x, skip=skip, upsample=upsample, act=HN.ACT_ELU, n_out=n_out)
 
 
 class DepthDecoder(nn.Module):
@@ -76,8 +77,14 @@ class DepthDecoder(nn.Module):
         for lvl in range(len(DEC_WIDTH) - 1, -1, -1):
             feat = self._block("reduce", lvl)(feat)
             skip = input_features[lvl - 1] if (self.use_skips and lvl > 0) else None
-            feat = self._block("merge", lvl)(feat, skip=skip, upsample=True)        # up-sampling + concatenation happen in the loader
+            # a level with a disparity head that is not the last one has two consumers: two aliases, so that backward sums the two gradients
+            # inside the ELU-backward kernel instead of through an autograd add
+            two = lvl in self.scales and lvl > 0 and torch.is_grad_enabled()
+            feat = self._block("merge", lvl)(feat, skip=skip, upsample=True, n_out=2 if two else 1)    # up-sampling + concatenation happen in the loader
+            head_in = feat
+            if two:
+                feat, head_in = feat
             if lvl in self.scales:
-                outputs["disp_logit", lvl] = self._block("head", lvl)(feat)
+                outputs["disp_logit", lvl] = self._block("head", lvl)(head_in)
         self.outputs = outputs
         return outputs

@@ -30,8 +30,8 @@ class HipConv2d(nn.Module):
             bound = 1.0 / math.sqrt(self.in_channels * self.kernel_size ** 2)
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x, skip=None, upsample=False, act=HN.ACT_NONE, bn_stats=False):
-        return HN.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.reflect, act, skip, upsample, bn_stats, owner=self)
+    def forward(self, x, skip=None, upsample=False, act=HN.ACT_NONE, bn_stats=False, n_out=1):
+        return HN.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.reflect, act, skip, upsample, bn_stats, owner=self, n_out=n_out)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}, reflect={self.reflect}"

@@ -116,7 +116,7 @@ class ResnetEncoder(nn.Module):
 
         if split:
             f0, f0_pool = conv_bn(e.conv1, e.bn1, x, n_out=2)            # decoder skip + max-pool
-            o1 = run(e.layer1, HN.max_pool_3x3_s2(f0_pool), 3)
+            o1 = run(e.layer1, HN.max_pool_3x3_s2(f0_pool, n_out=2), 3)    # first block: convolution + residual / down-sampling path
             o2 = run(e.layer2, (o1[1], o1[2]), 3)
             o3 = run(e.layer3, (o2[1], o2[2]), 3)
             f4 = run(e.layer4, (o3[1], o3[2]), 1)

@@ -18,6 +18,13 @@ class silog_loss(nn.Module):
     def forward(self, depth_est, depth_gt):
         return HP.silog_loss(depth_est, depth_gt, self.variance_focus)
 
+    def multi_scale(self, depth_ests, depth_gt, weights):
+        """sum_k weights[k] * forward(depth_ests[k], depth_gt): the per-scale loop of Supervised.py:L42-47 as one launch per phase."""
+        if len(depth_ests) > HP.MAX_SILOG_SCALES:
+            terms = [self.forward(e, depth_gt) * w for e, w in zip(depth_ests, weights)]
+            return sum(terms[1:], terms[0])
+        return HP.silog_loss_multi(depth_ests, depth_gt, self.variance_focus, weights)
+
 
 def variance_loss(depth):
     """losses.py:L16-18: 1 / mean((depth / mean(depth) - 1)^2) of one [B,1,h,w] fp32 depth map.  Two scalar reductions over a

@@ -18,6 +18,5 @@ class SupDepthModel(HipMetaArch):
             result["depth_pred"] = scales[0]
             return result
         # the nearest resize of the ground truth to each scale (Supervised.py:L44) happens inside the loss kernel
-        terms = [self.loss(pred, result["depth"]) for pred in scales]
-        result["silog_loss"] = self._weighted_sum(terms, [1.0 / len(scales)] * len(scales))
+        result["silog_loss"] = self.loss.multi_scale(list(scales), result["depth"], [1.0 / len(scales)] * len(scales))
         return result

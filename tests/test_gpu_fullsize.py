@@ -56,11 +56,11 @@ def layer_table():
     model = build(50, sd, "bf16").train()
     seen, orig = {}, HN.conv2d
 
-    def spy(x, weight, bias=None, stride=1, pad=0, reflect=False, act=0, skip=None, upsample=False, bn_stats=False, owner=None):
+    def spy(x, weight, bias=None, stride=1, pad=0, reflect=False, act=0, skip=None, upsample=False, bn_stats=False, owner=None, n_out=1):
         key = (x.shape[1], x.shape[2], x.shape[3], 0 if skip is None else skip.shape[3], weight.shape[0], weight.shape[2], int(stride), int(pad),
                bool(reflect), bias is not None, int(act), bool(upsample), bool(bn_stats))
         seen[key] = seen.get(key, 0) + 1
-        return orig(x, weight, bias, stride, pad, reflect, act, skip, upsample, bn_stats, owner)
+        return orig(x, weight, bias, stride, pad, reflect, act, skip, upsample, bn_stats, owner, n_out)
 
     HN.conv2d = spy
     try:

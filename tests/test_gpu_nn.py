@@ -650,3 +650,61 @@ def test_bn_bwd_finalize_apply_fused_equals_separate(NN, C, M, with_res, relu, n
     assert (dy1 != dy0).float().mean().item() < (2e-2 if wide else 1e-3)
     if with_res:
         assert torch.equal(dr1, dr0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("act,has_bias", [(1, True), (0, False), (0, True)])
+def test_conv_output_with_two_consumers(NN, dtype, act, has_bias):
+    """conv2d(..., n_out=2): two aliases of the (ELU) output -- a decoder level feeds its disparity head and the next level; backward gets the
+    two gradients separately and sums them inside the activation-backward kernel (sde_act_bwd_bias_sum)."""
+    g = torch.Generator().manual_seed(11 + act)
+    V = 4 if dtype == torch.float32 else 8
+    B, H, W, Cin, Cout = 2, 12, 20, 32, 64
+    x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g) * 0.1 if has_bias else None
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float(); w = w.bfloat16().float()
+    g0, g1 = torch.randn(B, Cout, H, W, generator=g), torch.randn(B, Cout, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        g0, g1 = g0.bfloat16().float(), g1.bfloat16().float()
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True) if has_bias else None
+    yr = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr, br)
+    if act == 1:
+        yr = F.elu(yr)
+    yr.backward(g0 + g1)
+    xd = nhwc(x, dtype, V).requires_grad_(True); wd = w.clone().to(dev).requires_grad_(True)
+    bd = b.clone().to(dev).requires_grad_(True) if has_bias else None
+    ya, yb = NN.conv2d(xd, wd, bd, stride=1, pad=1, reflect=True, act=act, n_out=2)
+    assert ya.data_ptr() == yb.data_ptr()
+    torch.autograd.backward([ya, yb], [nhwc(g0, dtype, V), nhwc(g1, dtype, V)])
+    check(wd.grad.cpu(), wr.grad, dtype, "dW")
+    check(nchw(xd.grad, Cin), xr.grad, dtype, "dX")
+    if has_bias:
+        check(bd.grad.cpu(), br.grad, dtype, "dbias")
+    # one consumer only: the other alias's gradient is None
+    xd2 = nhwc(x, dtype, V).requires_grad_(True)
+    ya, yb = NN.conv2d(xd2, wd, bd, stride=1, pad=1, reflect=True, act=act, n_out=2)
+    wd.grad = None
+    ya.backward(nhwc(g0 + g1, dtype, V))
+    check(nchw(xd2.grad, Cin), xr.grad, dtype, "dX one consumer")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_maxpool_two_consumers(NN, dtype):
+    g = torch.Generator().manual_seed(3)
+    V = 4 if dtype == torch.float32 else 8
+    B, C, H, W = 2, 64, 16, 24
+    x = torch.randn(B, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    g0, g1 = torch.randn(yr.shape, generator=g), torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        g0, g1 = g0.bfloat16().float(), g1.bfloat16().float()
+    yr.backward(g0 + g1)
+    xd = nhwc(x, dtype, V).requires_grad_(True)
+    ya, yb = NN.max_pool_3x3_s2(xd, n_out=2)
+    assert torch.equal(nchw(ya, C), yr.detach()) and ya.data_ptr() == yb.data_ptr()
+    torch.autograd.backward([ya, yb], [nhwc(g0, dtype, V), nhwc(g1, dtype, V)])
+    check(nchw(xd.grad, C), xr.grad, dtype, "maxpool dx (two consumers)", 1e-6, 2e-2)

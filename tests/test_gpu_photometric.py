@@ -229,6 +229,35 @@ def test_silog(P, B, h, w, H, W):
     close(ed.grad, eg.grad, 1e-4, 1e-9)
 
 
+@pytest.mark.parametrize("B,H,W,n", [(12, 192, 640, 4), (2, 64, 192, 3), (1, 48, 160, 1)])
+def test_silog_multi_scale(P, B, H, W, n):
+    """silog_loss_multi = sum_k w_k silog(est_k, nearest(gt)): per-scale statistics bit-identical to the single-scale launches (same block partition and
+    order), gradients equal to them, total and gradients against the oracle's per-scale loop (Supervised.py:L42-47)."""
+    g = torch.Generator().manual_seed(W + n)
+    gt = torch.where(torch.rand(B, 1, H, W, generator=g) < 0.3, torch.rand(B, 1, H, W, generator=g) * 79 + 1, torch.zeros(1))
+    ests = [torch.rand(B, 1, H >> k, W >> k, generator=g) * 60 + 0.3 for k in range(n)]
+    ws = [1.0 / n] * n
+    eo = [e.clone().requires_grad_(True) for e in ests]
+    lo = sum(OL.silog(e, G.resize_img(gt, e.shape[-2:], mode="nearest")) for e in eo) / n
+    lo.backward()
+    em = [e.clone().to(dev).requires_grad_(True) for e in ests]
+    lm = P.silog_loss_multi(em, gt.to(dev), 0.85, ws)
+    (lm * 3.0).backward()
+    es = [e.clone().to(dev).requires_grad_(True) for e in ests]
+    singles = [P.silog_loss(e, gt.to(dev), 0.85) for e in es]
+    ls = singles[0] * ws[0]
+    for t, w_ in zip(singles[1:], ws[1:]):
+        ls = ls + t * w_
+    (ls * 3.0).backward()
+    assert lm.shape == () and torch.equal(lm.cpu(), ls.cpu())
+    close(lm, lo, 2e-5, 1e-6)
+    for a_, b_, c_ in zip(em, es, eo):
+        close(a_.grad, b_.grad, 1e-6, 1e-12)
+        close(a_.grad / 3.0, c_.grad, 1e-4, 1e-9)
+    with pytest.raises(Exception):
+        P.silog_loss_multi(em, gt.to(dev), 0.85, ws[:-1] if n > 1 else [])
+
+
 def test_silog_golden(P, geo):
     for tag in ("s48", "s24"):
         D, gt = geo.t(f"{tag}.D"), geo.t(f"{tag}.gt")
