@@ -62,7 +62,7 @@ def build(args, device):
     torch.manual_seed(0)
     model = build_model(cfg).train()
     mk = T.supervised_trainer if wl["arch"] == "SupDepthModel" else T.monodepth2_trainer
-    trainer = mk(model, cfg, use_graph=not args.no_graph, overlap=(True if args.force_overlap else None))
+    trainer = mk(model, cfg, use_graph=not args.no_graph, overlap=(True if args.force_overlap else None), pose_stream=not args.no_pose_stream)
     return cfg, model, trainer
 
 
@@ -281,6 +281,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-overlap", action="store_true", help="use the two-phase backward (all-reduce overlap path) even on one GPU")
     ap.add_argument("--no-side-stream", action="store_true", help="weight-gradient GEMMs on the main stream (single-stream graph: profiling aid)")
+    ap.add_argument("--no-pose-stream", action="store_true", help="MonoDepth2: PoseNet on the main stream, after the depth network (A/B aid)")
     ap.add_argument("--const", action="append", default=[], metavar="NAME=INT", help="A/B aid: scheduling constant of hip/lib.py (JOIN_LAG, WGRAD_GROUP, DEFER_MAX_BYTES, FORK_MIN_BYTES ...)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sde_conv_set_option(KEY, VALUE) before the model is built (A/B measurements)")
     ap.add_argument("--no-pgemm", action="store_true", help="register-staged GEMM kernels only (A/B against the persistent LDS-DMA GEMM)")

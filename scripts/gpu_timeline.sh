@@ -52,7 +52,7 @@ last = rows[idx[-2] + 1: idx[-1] + 1]
 t0 = int(last[0]['Start_Timestamp'])
 S = lambda r: (int(r['Start_Timestamp']) - t0) / 1e3
 E = lambda r: (int(r['End_Timestamp']) - t0) / 1e3
-loss = next((i for i, r in enumerate(last) if 'silog_fwd' in r['Kernel_Name'] or 'photo_fwd' in r['Kernel_Name']), None)
+loss = next((i for i, r in enumerate(last) if ('silog_' in r['Kernel_Name'] and 'fwd' in r['Kernel_Name']) or 'photo_fwd' in r['Kernel_Name']), None)
 if loss is not None:
     fw, bw = last[:loss], last[loss:]
     print(f'forward: {len(fw)} kernels, {E(fw[-1]):.1f} us span, {sum(E(r) - S(r) for r in fw):.1f} us busy')

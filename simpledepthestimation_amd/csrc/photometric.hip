@@ -853,31 +853,33 @@ __global__ void __launch_bounds__(256) silog_multi_fwd_kernel(SilogScales a, con
     if (threadIdx.x == 0) part[blockIdx.x * 3 + 2] = s2;
 }
 
-// stats[k][0..3] as silog_finalize_kernel; total[0] = sum_k weight[k] * loss[k] (scales in order, fp32)
-__global__ void silog_multi_finalize_kernel(const float* __restrict__ part, SilogScales a, float vf, float* __restrict__ stats, float* __restrict__ total) {
-    __shared__ double sh[3][64];
+// stats[k][0..3] as silog_finalize_kernel; total[0] = sum_k weight[k] * loss[k] (scales in order, fp32).  One wave per scale, each doing exactly what the
+// single-scale finalize does (same lanes, same order), side by side.
+__global__ void __launch_bounds__(64 * SDE_SILOG_MAX_SCALES) silog_multi_finalize_kernel(const float* __restrict__ part, SilogScales a, float vf,
+                                                                                         float* __restrict__ stats, float* __restrict__ total) {
+    __shared__ double sh[SDE_SILOG_MAX_SCALES][3][64];
     __shared__ float loss[SDE_SILOG_MAX_SCALES];
-    const int t = threadIdx.x;
-    for (int k = 0; k < a.n; ++k) {
+    const int t = threadIdx.x & 63, k = threadIdx.x >> 6;
+    if (k < a.n) {
         const int first = k ? a.blk_end[k - 1] : 0, nblk = a.blk_end[k] - first;
         const float* p = part + (long)first * 3;
         double c = 0, s1 = 0, s2 = 0;
         for (int i = t; i < nblk; i += 64) { c += p[i * 3]; s1 += p[i * 3 + 1]; s2 += p[i * 3 + 2]; }
-        __syncthreads();
-        sh[0][t] = c; sh[1][t] = s1; sh[2][t] = s2;
-        __syncthreads();
-        if (t == 0) {
-            c = s1 = s2 = 0;
-            for (int i = 0; i < 64; ++i) { c += sh[0][i]; s1 += sh[1][i]; s2 += sh[2][i]; }
-            const double m1 = s1 / c, m2 = s2 / c;
-            stats[4 * k + 0] = (float)c; stats[4 * k + 1] = (float)m1; stats[4 * k + 2] = (float)m2;
-            loss[k] = (float)(sqrt(m2 - (double)vf * m1 * m1) * 10.0);
-            stats[4 * k + 3] = loss[k];
-        }
+        sh[k][0][t] = c; sh[k][1][t] = s1; sh[k][2][t] = s2;
     }
-    if (t == 0) {
+    __syncthreads();
+    if (k < a.n && t == 0) {
+        double c = 0, s1 = 0, s2 = 0;
+        for (int i = 0; i < 64; ++i) { c += sh[k][0][i]; s1 += sh[k][1][i]; s2 += sh[k][2][i]; }
+        const double m1 = s1 / c, m2 = s2 / c;
+        stats[4 * k + 0] = (float)c; stats[4 * k + 1] = (float)m1; stats[4 * k + 2] = (float)m2;
+        loss[k] = (float)(sqrt(m2 - (double)vf * m1 * m1) * 10.0);
+        stats[4 * k + 3] = loss[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         float s = 0.f;
-        for (int k = 0; k < a.n; ++k) s += a.weight[k] * loss[k];
+        for (int j = 0; j < a.n; ++j) s += a.weight[j] * loss[j];
         total[0] = s;
     }
 }
@@ -1172,7 +1174,7 @@ int sde_silog_multi_fwd(const float* const* est, const float* gt, int B, const i
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(silog_multi_fwd_kernel, dim3(a.blk_end[n - 1]), dim3(256), 0, s, a, gt, B, H, W, part);
     SDE_CHECK_LAUNCH("sde_silog_multi_fwd");
-    hipLaunchKernelGGL(silog_multi_finalize_kernel, dim3(1), dim3(64), 0, s, part, a, variance_focus, stats, total);
+    hipLaunchKernelGGL(silog_multi_finalize_kernel, dim3(1), dim3(64 * n), 0, s, part, a, variance_focus, stats, total);
     SDE_CHECK_LAUNCH("sde_silog_multi_fwd/finalize");
     return SDE_OK;
 }

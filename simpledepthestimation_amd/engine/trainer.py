@@ -74,7 +74,7 @@ class HipTrainer:
     """Owns the flat buffers and runs one training step: loss dict = trainer.step(batch)."""
 
     def __init__(self, model, groups, adamw=False, betas=(0.9, 0.999), eps=1e-8, bucket_mb=64, use_graph=False, skip_unused=(".fc.",),
-                 adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None, amp=False, init_scale=65536.0, growth_interval=2000):
+                 adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None, amp=False, init_scale=65536.0, growth_interval=2000, pose_stream=True):
         self.model = model
         L.apply_schedule("packnet" if any(type(m).__name__ == "PackNet01" for m in model.modules()) else "resnet")
         self._adam_fn = adam_fn or HN.adam_step      # tests on CPU (gloo) substitute a torch restatement of the same update
@@ -133,6 +133,8 @@ class HipTrainer:
                 owner._grad_cut = self._cut
         if self._cut is None:
             self.overlap = False
+        # MonoDepth2: PoseNet on the auxiliary stream underneath the depth network (hip/lib.py: POSE_STREAM); the two-phase backward keeps one stream
+        self.pose_stream = bool(pose_stream) and self._cut is None and adam_fn is None
         self._graph_b = None
         self._graph = None
         self._graphs = {}
@@ -224,7 +226,11 @@ class HipTrainer:
         self.gflat.zero_()
         if self._packer is not None:
             self._packer.run()                      # every conv operand of the step in one launch
-        out = self.model(batch)
+        L.POSE_STREAM = self.pose_stream and self.device.type == "cuda"
+        try:
+            out = self.model(batch)
+        finally:
+            L.POSE_STREAM = False
         loss_dict = {k: v for k, v in out.items() if "loss" in k}
         losses = sum(loss_dict.values())
         if self.amp:
@@ -247,11 +253,13 @@ class HipTrainer:
         HN.MAIN_STREAM = torch.cuda.current_stream() if self.device.type == "cuda" else None
         try:
             run()
+            L.join_aux()            # a network that ran on the auxiliary stream (PoseNet): its backward ran there as well
             if self._wreduce is not None:
                 self._wreduce.flush()
         finally:
             HN.WGRAD_DEFER = None
             HN.MAIN_STREAM = None
+            L.join_aux()            # (backward raised before the join above)
             if self._wreduce is not None:
                 self._wreduce.join_pending()
                 if self._wreduce.forked:                                  # backward raised before the flush: still join the side stream

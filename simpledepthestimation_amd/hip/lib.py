@@ -157,9 +157,36 @@ def side_stream(rotate=True):
     return _side[d][0]
 
 
+_aux = {}
+# MonoDepth2: PoseNet (seven small layers, every kernel of it launch-bound at batch 12) runs on an auxiliary stream underneath the depth network's forward
+# pass, and -- autograd replays a node's backward on the stream its forward ran on -- its backward underneath the depth network's backward.  HipTrainer
+# switches this on for single-process training (the two-phase backward of the data-parallel path keeps one stream).
+POSE_STREAM = False
+AUX_USED = False        # set by the forward pass that forked the auxiliary stream; the trainer joins it after backward
+
+
+def aux_stream():
+    d = torch.cuda.current_device()
+    if d not in _aux:
+        _aux[d] = torch.cuda.Stream(device=d)
+    return _aux[d]
+
+
+def is_aux_stream(st):
+    return any(st == a for a in _aux.values())
+
+
+def join_aux():
+    """Make the current stream wait for the auxiliary stream's work of this step (no-op when nothing was forked)."""
+    global AUX_USED
+    if AUX_USED:
+        torch.cuda.current_stream().wait_stream(aux_stream())
+        AUX_USED = False
+
+
 def all_side_streams():
     d = torch.cuda.current_device()
-    return list(_side.get(d, []))
+    return list(_side.get(d, [])) + ([_aux[d]] if d in _aux else [])
 
 
 def ptr_array(tensors):

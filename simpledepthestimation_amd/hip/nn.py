@@ -235,11 +235,14 @@ class _Conv2d(torch.autograd.Function):
         ldy = pad_to(Cout, V)
         if dy is None:
             return (None,) * 12
-        if MAIN_STREAM is not None and torch.cuda.current_stream() != MAIN_STREAM:
+        off_main = MAIN_STREAM is not None and torch.cuda.current_stream() != MAIN_STREAM
+        if off_main and not L.is_aux_stream(torch.cuda.current_stream()):
             # e.g. part of the forward pass ran under torch.cuda.stream(helper): autograd then replays this node's backward on that stream,
             # underneath fork / join events recorded against the trainer's stream (operands could be recycled while a GEMM still reads them)
             raise L.SdeHipError("conv2d backward is running on a different stream than the one the backward phase started on; the "
-                                "weight-gradient side-stream bookkeeping supports one main stream only")
+                                "weight-gradient side-stream bookkeeping supports one main stream (plus the registered auxiliary stream) only")
+        # off_main: a layer of the network that runs on the auxiliary stream (PoseNet): both of its GEMMs stay on that stream, in order -- no fork,
+        # no group queue; its slabs still join the phase's batched reduction, which the trainer launches after joining the auxiliary stream
         dy = dy.contiguous()
         M = B * OH * OW
         flops = 2.0 * M * Cout * KH * KW * Cin                    # algorithmic FLOPs of each of dgrad / wgrad
@@ -274,7 +277,7 @@ class _Conv2d(torch.autograd.Function):
                     esz = 4 if dt == torch.float32 else 2
                     meta = dict(M=M, N=Cout, K=KH * KW * (C0 + C1), k=KH, s=stride, mode=int(upcat), splits=splits,
                                 bytes=esz * (B * H0 * W0 * C0 + B * IH * IW * C1 + M * ldy) + 8 * splits * Cout * KH * KW * (C0 + C1))
-                forked = need_dx and L.SIDE_STREAM and L.PROFILE is None
+                forked = need_dx and L.SIDE_STREAM and L.PROFILE is None and not off_main
                 if forked and L.FORK_MIN_BYTES:      # (A/B aid, default 0: every layer forks)
                     forked = (dz.numel() + x0.numel() + (x1.numel() if x1 is not None else 0)) * dz.element_size() >= L.FORK_MIN_BYTES
                 # layers with very large operands (PackNet's full-resolution 64-channel maps: 190 MB each) fork on their own: holding three of

@@ -5,7 +5,9 @@ from collections import defaultdict
 
 import torch
 
+from ...hip import lib as L
 from ...hip import photometric as HP
+from ...utils.memory import to_cuda
 from ..losses.losses import silog_loss, variance_loss
 from ..losses.smoothness_loss import smoothness_loss
 from ..losses.ssim_loss import SSIM
@@ -25,14 +27,39 @@ class MonoDepth2Model(HipMetaArch):
         self.var_loss_w, self.sup_loss_w, self.smooth_loss_w = loss.VAR_LOSS_WEIGHT, loss.SUPERVISED_WEIGHT, loss.SMOOTHNESS_WEIGHT
         self.supervise_loss = silog_loss(loss.VARIANCE_FOCUS)
 
+    def _image_pyramid(self, batch):
+        """[(target image, [context images]) resized to each prediction scale]: the scales are those of the depth decoder, (H, W) >> i."""
+        image, contexts = batch["img_orig"], batch["ctx_img_orig"]
+        H, W = image.shape[-2:]
+        n = len(getattr(self.depth_net, "scales", range(4)))
+        if getattr(self.depth_net, "upsample_depth", False):
+            return None
+        return [(HP.resize(image, (H >> i, W >> i)), [HP.resize(c, (H >> i, W >> i)) for c in contexts]) for i in range(n)]
+
     def forward(self, batch):
-        batch = self.run_depth_net(batch)
         output = {}
         if not self.training:
+            batch = self.run_depth_net(batch)
             output["depth_pred"] = batch["depth_pred"][0]
             return output
-        batch["pose_net_input"] = torch.cat([batch["img"]] + batch["ctx_img"], 1)       # augmented frames, not normalised (L65)
-        batch = self.pose_net(batch)
+        batch = to_cuda(batch, self.device)
+        if L.POSE_STREAM and self.device.type == "cuda":
+            # PoseNet underneath the depth network: its kernels are launch-bound (seven small layers), the depth network's are not; autograd
+            # replays its backward on the same auxiliary stream, i.e. underneath the depth network's backward
+            cur, aux = torch.cuda.current_stream(), L.aux_stream()
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                batch["pose_net_input"] = torch.cat([batch["img"]] + batch["ctx_img"], 1)   # augmented frames, not normalised (L65)
+                batch = self.pose_net(batch)
+                pyramid = self._image_pyramid(batch)                                         # needs neither network: off the main stream as well
+            L.AUX_USED = True
+            batch = self.run_depth_net(batch)
+            cur.wait_stream(aux)
+        else:
+            batch = self.run_depth_net(batch)
+            batch["pose_net_input"] = torch.cat([batch["img"]] + batch["ctx_img"], 1)       # augmented frames, not normalised (L65)
+            batch = self.pose_net(batch)
+            pyramid = None
         image, contexts, intrinsics = batch["img_orig"], batch["ctx_img_orig"], batch["intrinsics"].float().contiguous()
         depth_pred, poses = batch["depth_pred"], batch["pose_pred"]
         num_scales = len(depth_pred)
@@ -42,8 +69,11 @@ class MonoDepth2Model(HipMetaArch):
         for i in range(num_scales):
             scale_w = 1.0 / 2 ** (num_scales - i - 1)
             h, w = depth_pred[i].shape[-2:]
-            resized_image = HP.resize(image, (h, w))
-            resized_targets = [HP.resize(c, (h, w)) for c in contexts]
+            if pyramid is not None and i < len(pyramid) and pyramid[i][0].shape[-2:] == (h, w):
+                resized_image, resized_targets = pyramid[i]
+            else:
+                resized_image = HP.resize(image, (h, w))
+                resized_targets = [HP.resize(c, (h, w)) for c in contexts]
             photo_losses.append(HP.photometric_scale_loss(depth_pred[i], intrinsics, resized_image, resized_targets, poses, w / W, h / H,
                                                           ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2,
                                                           automask=self.use_automask, reduce=self.photometric_reduce, clip=self.clip_loss))

@@ -266,6 +266,31 @@ def test_deferred_wgrad_reduce_equals_immediate(arch):
     assert res[1][0].abs().sum() > 0
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_posenet_on_the_auxiliary_stream_equals_the_single_stream_step(use_graph):
+    """MonoDepth2 with PoseNet on the auxiliary stream (underneath the depth network, forward and backward; HipTrainer's default for single-process
+    training) against the same steps with everything on one stream: losses, gradients and parameters bit for bit."""
+    from simpledepthestimation_amd.engine import trainer as T
+    sd = OM.init_state_dict(18, with_pose=True, seed=11)
+    batch = mono_batch(2, 64, 192, 12)
+    dbatch = {k: ([x.to(dev) for x in v] if isinstance(v, list) else v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    res = []
+    for pose_stream in (False, True):
+        model = build("MonoDepth2Model", 18, sd).train()
+        tr = T.monodepth2_trainer(model, make_cfg("MonoDepth2Model", 18), use_graph=use_graph, pose_stream=pose_stream)
+        assert tr.pose_stream == pose_stream
+        losses = []
+        for _ in range(3):
+            out = tr.step(clone_batch(dbatch))
+            losses.append({k: float(v) for k, v in out.items()})
+        torch.cuda.synchronize()
+        res.append((losses, tr.gflat.clone(), tr.pflat.clone()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]), "gradients differ"
+    assert torch.equal(res[0][2], res[1][2])
+    assert res[1][1].abs().sum() > 0
+
+
 def test_graph_replay_equals_eager():
     """The captured hipGraph step (zero-grad + batched weight pack + forward + backward) reproduces the eager step bit for bit."""
     from simpledepthestimation_amd.engine.trainer import supervised_trainer
