@@ -313,7 +313,7 @@ def main():
             k, v = kv.split("=")
             assert hasattr(L, k), k
             setattr(L, k, int(v))
-            if k in ("JOIN_LAG", "WGRAD_GROUP"):
+            if k in ("JOIN_LAG", "WGRAD_GROUP", "FIRST_GROUP"):
                 L.SCHEDULE_LOCKED = True
         for kv in args.opt:                     # A/B aid: --opt 6=128 -> sde_conv_set_option(SDE_OPT_WGRAD_BLOCKS, 128)
             k, v = kv.split("=")

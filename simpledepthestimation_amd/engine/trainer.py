@@ -76,7 +76,8 @@ class HipTrainer:
     def __init__(self, model, groups, adamw=False, betas=(0.9, 0.999), eps=1e-8, bucket_mb=64, use_graph=False, skip_unused=(".fc.",),
                  adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None, amp=False, init_scale=65536.0, growth_interval=2000, pose_stream=True):
         self.model = model
-        L.apply_schedule("packnet" if any(type(m).__name__ == "PackNet01" for m in model.modules()) else "resnet")
+        kinds = {type(m).__name__ for m in model.modules()}
+        L.apply_schedule("packnet" if "PackNet01" in kinds else "resnet" if ("Bottleneck" in kinds or "BasicBlock" not in kinds) else "resnet_basic")
         self._adam_fn = adam_fn or HN.adam_step      # tests on CPU (gloo) substitute a torch restatement of the same update
         self.adamw, self.betas, self.eps = bool(adamw), betas, float(eps)
         self.use_graph = bool(use_graph)
@@ -267,7 +268,7 @@ class HipTrainer:
                         torch.cuda.current_stream().wait_stream(st_)
                     self._wreduce.forked = False
                 self._wreduce.jobs, self._wreduce._seen = [], set()       # nothing left registered if backward raised
-                self._wreduce.queue = []
+                self._wreduce.queue, self._wreduce.groups_done = [], 0
 
     def _backward_rest(self):
         self._backward(self._cut.backward_rest)

@@ -133,14 +133,18 @@ WGRAD_GROUP = 6         # weight-gradient GEMMs of that many consecutive layers 
 #   round 2 (LDS-DMA / halo weight gradients, faster slab sums: the side queue got a third shorter), Supervised-R50: (lag, group) = (2, 3) 7.21,
 #   (1, 3) 7.09, (1, 4) 7.10, (1, 5) 7.06, (1, 6) 6.98-7.00, (1, 7) 7.10, (1, 8) 7.00, (1, 10) 7.07, (0, 6) 6.98, (0, 8) 7.00, (2, 8) 7.13;
 #   MonoDepth2-R18 5.48 -> 5.33, R50 8.98 -> 8.74 with (1, 6); PackNet-1A the other way: (2, 3) 53.8, (1, 3) 55.9, (1, 6) 56.0 ms/step.
-SCHEDULES = {"resnet": (1, 6), "packnet": (2, 3)}
+#   FIRST_GROUP (layers in the first group of a phase; until it closes nothing runs next to the chain; it also shifts every later group boundary):
+#   bottleneck ResNets 0 (= 6) 6.77 against 6.89-6.94 ms/step for 1 / 2 / 3 / 4 / 5 / 7 / 8 / 9 (Supervised-R50), MonoDepth2-R50 8.06 vs 8.09 at 3;
+#   basic-block ResNets 3: Supervised-R18 3.50 -> 3.42, MonoDepth2-R18 4.69 -> 4.60 (2: 4.62, 4: 4.74, 5: 4.66).
+SCHEDULES = {"resnet": (1, 6, 0), "resnet_basic": (1, 6, 3), "packnet": (2, 3, 0)}
 SCHEDULE_LOCKED = False  # bench.py --const JOIN_LAG=... / WGRAD_GROUP=... pins the values for an A/B run
 
 
 def apply_schedule(family):
-    global JOIN_LAG, WGRAD_GROUP
+    global JOIN_LAG, WGRAD_GROUP, FIRST_GROUP
     if not SCHEDULE_LOCKED:
-        JOIN_LAG, WGRAD_GROUP = SCHEDULES[family]
+        JOIN_LAG, WGRAD_GROUP, FIRST_GROUP = SCHEDULES[family]
+FIRST_GROUP = 0                 # layers in the FIRST group of a backward phase (0: WGRAD_GROUP like the others); set per network family (SCHEDULES)
 GROUP_MAX_BYTES = 128 << 20     # layers with more operand bytes fork alone (PackNet's 190 MB maps: 57.7 vs 60.2 ms/step)
 GROUP_BUDGET_BYTES = 384 << 20  # ... and a group also closes once its layers' operands add up to this much
 DEFER_MAX_BYTES = 2 << 20       # slab stacks up to this size join the phase's batched reduction; bigger ones are summed at once, cache-resident

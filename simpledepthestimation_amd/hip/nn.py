@@ -333,7 +333,8 @@ class _Conv2d(torch.autograd.Function):
                     WGRAD_DEFER.queue.append((launch, (dz, x0, x1, slab, dw)))
                     WGRAD_DEFER.queue_bytes += op_bytes
                     # a group closes after WGRAD_GROUP layers or once its operands (kept alive until the group's GEMMs ran) exceed the byte budget
-                    if len(WGRAD_DEFER.queue) >= L.WGRAD_GROUP or WGRAD_DEFER.queue_bytes >= L.GROUP_BUDGET_BYTES:
+                    limit = L.FIRST_GROUP if (L.FIRST_GROUP and WGRAD_DEFER.groups_done == 0) else L.WGRAD_GROUP
+                    if len(WGRAD_DEFER.queue) >= limit or WGRAD_DEFER.queue_bytes >= L.GROUP_BUDGET_BYTES:
                         WGRAD_DEFER.run_queue()
                     st["dw"], st["forked"], st["side"] = (None if wslot is not None else dw), False, None
                     return
@@ -426,6 +427,7 @@ class WGradReducer:
         self.pending = []          # (event behind a layer's side-stream work, its operands) of convolutions whose join is lagging (SDE_JOIN_LAG)
         self.queue = []            # SDE_WGRAD_GROUP > 1: (launch closure, operands) of layers whose weight-gradient GEMM waits for its group's fork
         self.queue_bytes = 0       # operand bytes held by the queued layers
+        self.groups_done = 0       # groups forked so far in this backward phase (the first one may be shorter: hip.lib.FIRST_GROUP)
 
     def run_queue(self):
         """SDE_WGRAD_GROUP > 1: launch the queued weight-gradient GEMMs of the last few layers behind ONE fork of the side stream (one
@@ -444,6 +446,7 @@ class WGradReducer:
         ev.record(side)
         self.pending.append((ev, refs))
         self.queue, self.queue_bytes = [], 0
+        self.groups_done += 1
 
     def join_pending(self, keep=0):
         """Make the current stream wait for all but the newest `keep` lagging weight-gradient GEMMs and release their operands."""
@@ -461,6 +464,7 @@ class WGradReducer:
 
     def flush(self):
         self.run_queue()
+        self.groups_done = 0
         self.join_pending()
         if self.forked:
             for st_ in L.all_side_streams():
