@@ -144,7 +144,8 @@ def apply_schedule(family):
     global JOIN_LAG, WGRAD_GROUP, FIRST_GROUP
     if not SCHEDULE_LOCKED:
         JOIN_LAG, WGRAD_GROUP, FIRST_GROUP = SCHEDULES[family]
-FIRST_GROUP = 0                 # layers in the FIRST group of a backward phase (0: WGRAD_GROUP like the others); set per network family (SCHEDULES)
+FIRST_GROUP = 0                 # sizes of the first groups of a backward phase as decimal digits (3: the first group has 3 layers; 33: the first two), 0: none;
+                                # set per network family (SCHEDULES)
 GROUP_MAX_BYTES = 128 << 20     # layers with more operand bytes fork alone (PackNet's 190 MB maps: 57.7 vs 60.2 ms/step)
 GROUP_BUDGET_BYTES = 384 << 20  # ... and a group also closes once its layers' operands add up to this much
 DEFER_MAX_BYTES = 2 << 20       # slab stacks up to this size join the phase's batched reduction; bigger ones are summed at once, cache-resident

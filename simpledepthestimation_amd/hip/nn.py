@@ -333,7 +333,8 @@ class _Conv2d(torch.autograd.Function):
                     WGRAD_DEFER.queue.append((launch, (dz, x0, x1, slab, dw)))
                     WGRAD_DEFER.queue_bytes += op_bytes
                     # a group closes after WGRAD_GROUP layers or once its operands (kept alive until the group's GEMMs ran) exceed the byte budget
-                    limit = L.FIRST_GROUP if (L.FIRST_GROUP and WGRAD_DEFER.groups_done == 0) else L.WGRAD_GROUP
+                    prefix = str(L.FIRST_GROUP) if L.FIRST_GROUP else ""      # decimal digits = sizes of the first groups of the phase (33: 3 then 3)
+                    limit = int(prefix[WGRAD_DEFER.groups_done]) if WGRAD_DEFER.groups_done < len(prefix) else L.WGRAD_GROUP
                     if len(WGRAD_DEFER.queue) >= limit or WGRAD_DEFER.queue_bytes >= L.GROUP_BUDGET_BYTES:
                         WGRAD_DEFER.run_queue()
                     st["dw"], st["forked"], st["side"] = (None if wslot is not None else dw), False, None
