@@ -624,10 +624,44 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
         const long total = M * cch;
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long stride = (long)gridDim.x * 256;
+        long i = (long)blockIdx.x * 256 + threadIdx.x;
+        // four items per round trip: narrow full-resolution tensors (the disparity heads: 8-16 channels) give a thread only a handful of items, and
+        // one dependent load at a time left the pass latency-bound (26 us for 24 MB)
+        for (; i + 3 * stride < total; i += 4 * stride) {
+            float d[4][V], o[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load_vec<T>(dout + (i + u * stride) * V, d[u]);
+            if (dout1) {              // second consumer of the activation (decoder level -> its disparity head and the next level)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load_vec<T>(dout1 + (i + u * stride) * V, o[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) d[u][e] += o[u][e];
+            }
+            if (act != SDE_ACT_NONE) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load_vec<T>(out + (i + u * stride) * V, o[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        if (act == SDE_ACT_ELU) d[u][e] = o[u][e] > 0.f ? d[u][e] : d[u][e] * (o[u][e] + 1.0f);     // ELU'(x) = exp(x) = out + 1 for x <= 0
+                        else d[u][e] = o[u][e] > 0.f ? d[u][e] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (dz) store_vec<T>(dz + (i + u * stride) * V, d[u]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += d[u][e];
+            }
+        }
+        for (; i < total; i += stride) {
             float d[V], o[V];
             load_vec<T>(dout + i * V, d);
-            if (dout1) {              // second consumer of the activation (decoder level -> its disparity head and the next level)
+            if (dout1) {
                 load_vec<T>(dout1 + i * V, o);
 #pragma unroll
                 for (int e = 0; e < V; ++e) d[e] += o[e];
@@ -636,7 +670,7 @@ __global__ void __launch_bounds__(256) act_bwd_bias_kernel(const T* __restrict__
                 load_vec<T>(out + i * V, o);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    if (act == SDE_ACT_ELU) d[e] = o[e] > 0.f ? d[e] : d[e] * (o[e] + 1.0f);     // ELU'(x) = exp(x) = out + 1 for x <= 0
+                    if (act == SDE_ACT_ELU) d[e] = o[e] > 0.f ? d[e] : d[e] * (o[e] + 1.0f);
                     else d[e] = o[e] > 0.f ? d[e] : 0.f;
                 }
             }

@@ -142,6 +142,7 @@ class HipTrainer:
         self._static_batch = None
         self._static_out = None
         self._packer = None            # built lazily after the first eager step (needs the operand shapes seen in forward)
+        self._one = None
         self.batch_pack = adam_fn is None
         # one weight-gradient slab reduction launch per backward phase
         self._wreduce = HN.WGradReducer() if adam_fn is None else None
@@ -233,12 +234,17 @@ class HipTrainer:
         finally:
             L.POSE_STREAM = False
         loss_dict = {k: v for k, v in out.items() if "loss" in k}
-        losses = sum(loss_dict.values())
+        terms = list(loss_dict.values())
+        losses = terms[0]                               # (python's sum() starts from int 0: an add-scalar kernel on the serial seam of the step)
+        for t in terms[1:]:
+            losses = losses + t
         if self.amp:
             losses = losses * self.scale_state[0]       # GradScaler.scale(loss): a device scalar, so the multiply is part of the captured graph
         if self._packer is not None:
             self._packer.join_dgrad()
-        self._backward(lambda: losses.backward())
+        if self._one is None or self._one.dtype != losses.dtype or self._one.device != losses.device or self._one.shape != losses.shape:
+            self._one = torch.ones_like(losses)         # d loss / d loss, kept: backward() would launch a fill for it every step
+        self._backward(lambda: losses.backward(gradient=self._one))
         if self._packer is None and self.batch_pack:
             try:
                 self._packer = HN.WeightPacker(self.model)
