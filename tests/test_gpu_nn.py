@@ -612,13 +612,13 @@ def test_bn_finalize_apply_fused_equals_separate(NN, C, R, with_res, relu, dtype
 
 @pytest.mark.parametrize("C,M,with_res,relu,n_grads", [(256, 5760, False, True, 1), (512, 1440, True, True, 2), (1024, 1445, True, False, 3), (64, 3000, False, True, 1),
                                                          (256, 23040, True, True, 2), (64, 92163, False, True, 1), (2048, 1441, True, True, 1)])      # the last three: 1024-thread reduce
-def test_bn_bwd_finalize_apply_fused_equals_separate(NN, C, M, with_res, relu, n_grads):
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_bn_bwd_finalize_apply_fused_equals_separate(NN, C, M, with_res, relu, n_grads, dt):
     """sde_bn_bwd with its finalize + apply passes in one launch (short partial slabs; big layers: 1024-thread reduce workgroups keep the slab
     short) against the three-launch form (sde_bn_set_fuse(0)):
     dy equal up to one bf16 ulp on a handful of elements, parameter gradients to 1e-6 (fp64 column sums in a different order)."""
     from simpledepthestimation_amd.hip import lib as L
     g = torch.Generator().manual_seed(C + M)
-    dt = torch.bfloat16
     y = (torch.randn(M, C, generator=g) * 1.3 + 0.1).to(dt)
     res = torch.randn(M, C, generator=g).to(dt) if with_res else None
     gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
@@ -646,7 +646,7 @@ def test_bn_bwd_finalize_apply_fused_equals_separate(NN, C, M, with_res, relu, n
     tol = 2e-5 if wide else 1e-6
     assert torch.allclose(dg1, dg0, rtol=tol, atol=tol * float(dg0.abs().max())) and torch.allclose(db1, db0, rtol=tol, atol=tol * float(db0.abs().max()))
     bad = ((dy1 - dy0).abs() > 2.0 ** -7 * torch.maximum(dy1.abs(), dy0.abs()) + 1e-6).sum().item()
-    assert bad == 0, f"{bad} of {dy1.numel()} elements of dy differ by more than one bf16 ulp"
+    assert bad == 0, f"{bad} of {dy1.numel()} elements of dy differ by more than one bf16 ulp (fp16: the same bound, eight of its ulps)"
     assert (dy1 != dy0).float().mean().item() < (2e-2 if wide else 1e-3)
     if with_res:
         assert torch.equal(dr1, dr0)
