@@ -40,6 +40,18 @@ struct Cam {
     float k[9];    // scaled intrinsics (camera.py:L14-22)
 };
 
+// The camera of a (sample, context) is the same for every lane of a workgroup: moved into scalar registers (v_readfirstlane), its 30 values stop
+// occupying vector registers across the projection / VJP code (the backward kernel is register-bound: 120 VGPRs = 4 waves per SIMD with them in VGPRs).
+__device__ __forceinline__ float sde_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ Cam cam_uniform(const Cam& c) {
+    Cam u;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { u.ki[i] = sde_uniform(c.ki[i]); u.kr[i] = sde_uniform(c.kr[i]); u.k[i] = sde_uniform(c.k[i]); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u.kt[i] = sde_uniform(c.kt[i]);
+    return u;
+}
+
 __device__ __forceinline__ void make_cam(const float* __restrict__ K, const float* __restrict__ P, float sx, float sy,
                                          Cam& c) {
 #pragma unroll
@@ -350,8 +362,11 @@ struct PhotoBwdArgs {
     float sx, sy, ssim_w, C1, C2, gscale;   // gscale = 1/(B*h*w)  (mean over pixels)
 };
 
-template <int NCTX>
-__global__ void __launch_bounds__(BT_N) photo_bwd_kernel(PhotoBwdArgs a) {
+// DENSE: the instantiation for grids that fill the GPU several times over (the two fine scales): compiled for six waves per SIMD (80 VGPRs, three
+// workgroups per CU; seven values spill) -- 164 -> 145 us at 192x640, 55 -> 50 at 96x320; the coarse scales, whose grids do not fill the CUs, keep
+// the spill-free 92-VGPR form (they lose 15 % with the spills: 22.7 -> 26.1, 17.5 -> 20.2 us)
+template <int NCTX, bool DENSE = false>
+__global__ void __launch_bounds__(BT_N, DENSE ? 6 : 1) photo_bwd_kernel(PhotoBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sA = lds;                  // [3][BT_N]
     float* sX = sA + 3 * BT_N;        // [3][BT_N]     current context's warped sample
@@ -424,7 +439,7 @@ __global__ void __launch_bounds__(BT_N) photo_bwd_kernel(PhotoBwdArgs a) {
         float acc12[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) acc12[i] = 0.f;
-        const Cam cam = scam[j];
+        const Cam cam = cam_uniform(scam[j]);
         if (interior) {
             float ds[3];
             const float l1w = a.reduce_mean ? (mean_on ? g_mean : 0.f) : (mysel == mi ? g : 0.f);
@@ -1049,9 +1064,13 @@ int sde_photo_bwd(const sde_photo_desc* d, const float* const* sampled, const ui
     dim3 grid(sde_cdiv(d->w, BT_W - 4), sde_cdiv(d->h, BT_H - 4), d->B), blk(BT_W, BT_H);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = photo_bwd_lds();
+    const bool dense = (long)grid.x * grid.y * grid.z >= 1024;      // the grid fills three workgroups per CU (768) with a second round to spare
     switch (d->nctx) {
         case 1: hipLaunchKernelGGL(photo_bwd_kernel<1>, grid, blk, lds, s, a); break;
-        case 2: hipLaunchKernelGGL(photo_bwd_kernel<2>, grid, blk, lds, s, a); break;
+        case 2:
+            if (dense) hipLaunchKernelGGL((photo_bwd_kernel<2, true>), grid, blk, lds, s, a);
+            else hipLaunchKernelGGL(photo_bwd_kernel<2>, grid, blk, lds, s, a);
+            break;
         case 3: hipLaunchKernelGGL(photo_bwd_kernel<3>, grid, blk, lds, s, a); break;
         default: hipLaunchKernelGGL(photo_bwd_kernel<4>, grid, blk, lds, s, a); break;
     }
