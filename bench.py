@@ -319,6 +319,8 @@ def main():
             k, v = kv.split("=")
             if k == "bn_fuse":                  # --opt bn_fuse=2 -> sde_bn_set_fuse(2)
                 L.lib().sde_bn_set_fuse(int(v))
+            elif k == "head_bias":              # --opt head_bias=0 -> disparity-head bias gradients by the separate pass
+                HN.HEAD_BIAS_FUSED = bool(int(v))
             else:
                 HN.set_option(int(k), int(v))
         if args.no_side_stream:

@@ -284,6 +284,11 @@ int sde_refl_fold(const void* dxp, int B, int H, int W, int C, int C0, int upcat
 int sde_depth_head_fwd(const void* y, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, float* depth, sde_stream_t stream);
 int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, void* dy,
                        sde_stream_t stream);
+/* ... also producing the bias gradient of the one-channel convolution in front of the head (depth_decoder.py:L95-97 `dispconv`): dbias[0] (+)= sum of the
+ * logit gradients as stored in dy.  part: [sde_depth_head_bias_blocks(B, H, W)] floats; part and dbias are given together or both NULL. */
+int sde_depth_head_bias_blocks(int B, int H, int W);
+int sde_depth_head_bwd_bias(const void* y, const float* ddepth, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, void* dy,
+                            float* part, float* dbias, int accumulate, sde_stream_t stream);
 
 /* nn.GroupNorm(G) + activation: relu = 0 none, 1 nn.ReLU (PoseNet.py:L13-20), 2 nn.ELU (layers01.py:L33-40).
  * part: [B][SDE_GN_CHUNKS][C][2] workspace, gnp: [B][G][2] (mean, rstd) saved for backward, coef: [B][G][2] workspace. */

@@ -830,8 +830,10 @@ __global__ void __launch_bounds__(256) depth_head_fwd_kernel(const T* __restrict
 
 template <typename T>
 __global__ void __launch_bounds__(256) depth_head_bwd_kernel(const T* __restrict__ y, const float* __restrict__ ddepth, int B, int H, int W, int ld,
-                                                             float min_disp, float max_disp, int flip, T* __restrict__ dy) {
+                                                             float min_disp, float max_disp, int flip, T* __restrict__ dy, float* __restrict__ bias_part) {
+    __shared__ float red[16];
     const long n = (long)B * H * W;
+    float bsum = 0.f;       // sum of the (storage-rounded) logit gradients of this workgroup: the bias gradient of the one-channel convolution in front
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float v = (float)y[i * ld];
         const float sp = v > 20.f ? v : log1pf(expf(v));
@@ -842,8 +844,22 @@ __global__ void __launch_bounds__(256) depth_head_bwd_kernel(const T* __restrict
         const float g = ddepth[o] * (-1.0f / (sd * sd)) * (max_disp - min_disp) * dsp;
         T* d = dy + i * ld;
         d[0] = (T)g;
+        bsum += (float)(T)g;
         for (int c = 1; c < ld; ++c) d[c] = (T)0.f;
     }
+    if (bias_part) {
+        bsum = sde_block_sum(bsum, red);
+        if (threadIdx.x == 0) bias_part[blockIdx.x] = bsum;
+    }
+}
+
+// dbias[0] (+)= sum of the per-workgroup partials of depth_head_bwd_kernel, fixed order
+__global__ void __launch_bounds__(256) head_bias_finalize_kernel(const float* __restrict__ part, int n, float* __restrict__ dbias, int accumulate) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = sde_block_sum(s, red);
+    if (threadIdx.x == 0) dbias[0] = accumulate ? dbias[0] + s : s;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1461,14 +1477,26 @@ int sde_depth_head_fwd(const void* y, int B, int H, int W, int ld, float min_dep
 
 int sde_depth_head_bwd(const void* y, const float* ddepth, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, void* dy,
                        sde_stream_t stream) {
+    return sde_depth_head_bwd_bias(y, ddepth, B, H, W, ld, min_depth, max_depth, flip, dtype, dy, nullptr, nullptr, 0, stream);
+}
+
+int sde_depth_head_bias_blocks(int B, int H, int W) { return grid_for((long)B * H * W); }
+
+int sde_depth_head_bwd_bias(const void* y, const float* ddepth, int B, int H, int W, int ld, float min_depth, float max_depth, int flip, int dtype, void* dy,
+                            float* part, float* dbias, int accumulate, sde_stream_t stream) {
     SDE_CHECK_ARG(y && ddepth && dy && B > 0 && H > 0 && W > 0 && ld > 0, "sde_depth_head_bwd: bad argument");
+    SDE_CHECK_ARG((part == nullptr) == (dbias == nullptr), "sde_depth_head_bwd_bias: the bias gradient needs both the partial buffer and the output");
     hipStream_t s = (hipStream_t)stream;
     const float mind = 1.0f / max_depth, maxd = 1.0f / min_depth;
     const int nb = grid_for((long)B * H * W);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(depth_head_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)y, ddepth, B, H, W, ld, mind, maxd, flip, (float*)dy),
-               hipLaunchKernelGGL(depth_head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, ddepth, B, H, W, ld, mind, maxd, flip, (bf16_t*)dy),
-               hipLaunchKernelGGL(depth_head_bwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)y, ddepth, B, H, W, ld, mind, maxd, flip, (half_t*)dy));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(depth_head_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)y, ddepth, B, H, W, ld, mind, maxd, flip, (float*)dy, part),
+               hipLaunchKernelGGL(depth_head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)y, ddepth, B, H, W, ld, mind, maxd, flip, (bf16_t*)dy, part),
+               hipLaunchKernelGGL(depth_head_bwd_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)y, ddepth, B, H, W, ld, mind, maxd, flip, (half_t*)dy, part));
     SDE_CHECK_LAUNCH("sde_depth_head_bwd");
+    if (dbias) {
+        hipLaunchKernelGGL(head_bias_finalize_kernel, dim3(1), dim3(256), 0, s, part, nb, dbias, accumulate);
+        SDE_CHECK_LAUNCH("sde_depth_head_bwd_bias/finalize");
+    }
     return SDE_OK;
 }
 

@@ -48,6 +48,8 @@ L.register_protos({
     "sde_reduce_num_blocks": ([_LG, _I], c_int),
     "sde_bn_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _LG, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P], c_int),
     "sde_maxpool_fwd": ([_P, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
+    "sde_depth_head_bias_blocks": ([_I, _I, _I], c_int),
+    "sde_depth_head_bwd_bias": ([_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P, _P, _I, _P], c_int),
     "sde_maxpool_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_maxpool_bwd_sum": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_act_bwd_bias": ([_P, _P, _I, _LG, _I, _I, _P, _P, _P, _I, _I, _P], c_int),
@@ -207,6 +209,10 @@ class _Conv2d(torch.autograd.Function):
         ctx.params = (weight, bias)
         ctx.cfg = (stride, pad, reflect, act, upcat, bias is not None, IH, IW, OH, OW)
         ctx.want_stats = want_stats
+        if HEAD_BIAS_FUSED and bias is not None and act == ACT_NONE and Cout == 1 and not want_stats and n_out == 1:
+            if len(_HEAD_SLOT) > 64:
+                _HEAD_SLOT.clear()
+            _HEAD_SLOT[y.data_ptr()] = bias           # a disparity head: depth_head's backward can produce this layer's bias gradient on its way
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -249,7 +255,9 @@ class _Conv2d(torch.autograd.Function):
         # 1. activation backward + bias gradient
         dbias = None
         dz = dy
-        if act != ACT_NONE or has_bias or dy1 is not None:
+        # (the depth head's backward already summed this one-channel layer's bias gradient into its slot: nothing left to do in this step)
+        head_did_bias = has_bias and act == ACT_NONE and dy1 is None and _HEAD_DONE.pop(dy.data_ptr(), None) == id(ctx.params[1])
+        if (act != ACT_NONE or has_bias or dy1 is not None) and not head_did_bias:
             nblk = lib.sde_reduce_num_blocks(M, ldy)
             part = torch.empty(nblk + REDUCE_ROWS, ldy, device=dev) if has_bias else None
             bslot = _grad_slot(ctx.params[1]) if has_bias else None
@@ -699,9 +707,15 @@ def prep_input(img, mean, std, dtype, flip=False):
     return out
 
 
+HEAD_BIAS_FUSED = True   # the bias gradient of a one-channel convolution feeding depth_head comes out of depth_head's backward (False: separate pass; tests)
+_HEAD_SLOT = {}     # data_ptr of a one-channel bias convolution's output -> its bias parameter (set by _Conv2d.forward, taken by _DepthHead.forward)
+_HEAD_DONE = {}     # data_ptr of the logit gradient _DepthHead.backward returned -> id(bias parameter) whose gradient it accumulated
+
+
 class _DepthHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, min_depth, max_depth, flip):
+        ctx.bias_param = _HEAD_SLOT.pop(y.data_ptr(), None)
         B, H, W, ld = y.shape
         depth = torch.empty(B, 1, H, W, device=y.device, dtype=torch.float32)
         L.check(L.lib().sde_depth_head_fwd(L.ptr(y.contiguous()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype), L.ptr(depth), L.stream()),
@@ -716,7 +730,19 @@ class _DepthHead(torch.autograd.Function):
         min_depth, max_depth, flip = ctx.cfg
         B, H, W, ld = y.shape
         dy = torch.empty_like(y)
-        L.check(L.lib().sde_depth_head_bwd(L.ptr(y), L.ptr(ddepth.contiguous().float()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype),
+        lib = L.lib()
+        bslot = _grad_slot(ctx.bias_param) if ctx.bias_param is not None else None
+        if bslot is not None and bslot.numel() == 1:
+            # the convolution in front has ONE output channel: its bias gradient is the sum of the logit gradients this kernel writes -- summed here,
+            # into the flat gradient, instead of by a separate pass over the (8-channel padded) gradient tensor in the convolution's backward
+            part = torch.empty(lib.sde_depth_head_bias_blocks(B, H, W), device=y.device)
+            L.check(lib.sde_depth_head_bwd_bias(L.ptr(y), L.ptr(ddepth.contiguous().float()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype),
+                                                L.ptr(dy), L.ptr(part), L.ptr(bslot), 1, L.stream()), "sde_depth_head_bwd_bias")
+            if len(_HEAD_DONE) > 64:
+                _HEAD_DONE.clear()
+            _HEAD_DONE[dy.data_ptr()] = id(ctx.bias_param)
+        else:
+            L.check(lib.sde_depth_head_bwd(L.ptr(y), L.ptr(ddepth.contiguous().float()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype),
                                            L.ptr(dy), L.stream()), "sde_depth_head_bwd")
         return dy, None, None, None
 

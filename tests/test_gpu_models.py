@@ -291,6 +291,32 @@ def test_posenet_on_the_auxiliary_stream_equals_the_single_stream_step(use_graph
     assert res[1][1].abs().sum() > 0
 
 
+def test_head_bias_gradient_from_the_depth_head_backward():
+    """The disparity heads' bias gradients summed inside depth_head's backward (trainer path: straight into the flat gradient) against the separate
+    activation-backward pass over the padded gradient tensor: the same summands in another order."""
+    from simpledepthestimation_amd.engine.trainer import supervised_trainer
+    from simpledepthestimation_amd.hip import nn as HN
+    sd = OM.init_state_dict(18, seed=11)
+    batch = {k: v.to(dev) for k, v in sup_batch(2, 64, 192, 12).items()}
+    res = []
+    for fused in (False, True):
+        HN.HEAD_BIAS_FUSED = fused
+        try:
+            model = build("SupDepthModel", 18, sd, "bf16").train()
+            tr = supervised_trainer(model, make_cfg("SupDepthModel", 18, "bf16"))
+            tr.step(clone_batch(batch))
+            torch.cuda.synchronize()
+            names = [n for n, p in model.named_parameters() if n.endswith("conv.bias") and p.numel() == 1]
+            res.append((tr.gflat.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if n in names}))
+        finally:
+            HN.HEAD_BIAS_FUSED = True
+    assert len(res[1][1]) == 4, list(res[1][1])
+    for n, g in res[1][1].items():
+        assert torch.allclose(g, res[0][1][n], rtol=2e-5, atol=1e-7) and float(g.abs()) > 0, (n, g, res[0][1][n])
+    others = (res[0][0] - res[1][0]).abs()
+    assert int((others > 0).sum()) <= 4      # nothing but the four bias gradients may differ at all
+
+
 def test_graph_replay_equals_eager():
     """The captured hipGraph step (zero-grad + batched weight pack + forward + backward) reproduces the eager step bit for bit."""
     from simpledepthestimation_amd.engine.trainer import supervised_trainer
