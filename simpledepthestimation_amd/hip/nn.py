@@ -4,6 +4,7 @@ Tensor convention: activations are NHWC torch tensors [B, H, W, C] (float32, bfl
 parameters stay fp32 in the reference's layouts (conv weight OIHW) so state dicts are interchangeable.
 """
 import ctypes
+import weakref
 import os
 from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_long, c_void_p
 
@@ -212,7 +213,10 @@ class _Conv2d(torch.autograd.Function):
         if HEAD_BIAS_FUSED and bias is not None and act == ACT_NONE and Cout == 1 and not want_stats and n_out == 1:
             if len(_HEAD_SLOT) > 64:
                 _HEAD_SLOT.clear()
-            _HEAD_SLOT[y.data_ptr()] = bias           # a disparity head: depth_head's backward can produce this layer's bias gradient on its way
+            _HEAD_DONE.clear()                        # (entries live from a head's backward to its convolution's backward only: none survives into a new forward)
+            # a disparity head: depth_head's backward can produce this layer's bias gradient on its way.  The weak reference pins the entry to THIS
+            # output tensor object (Function.apply hands the same object to the caller), so an address reused by another tensor never matches
+            _HEAD_SLOT[y.data_ptr()] = (bias, weakref.ref(y))
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -707,6 +711,7 @@ def prep_input(img, mean, std, dtype, flip=False):
     return out
 
 
+HEAD_BIAS_HITS = 0       # times the fused path below ran (tests)
 HEAD_BIAS_FUSED = True   # the bias gradient of a one-channel convolution feeding depth_head comes out of depth_head's backward (False: separate pass; tests)
 _HEAD_SLOT = {}     # data_ptr of a one-channel bias convolution's output -> its bias parameter (set by _Conv2d.forward, taken by _DepthHead.forward)
 _HEAD_DONE = {}     # data_ptr of the logit gradient _DepthHead.backward returned -> id(bias parameter) whose gradient it accumulated
@@ -715,7 +720,8 @@ _HEAD_DONE = {}     # data_ptr of the logit gradient _DepthHead.backward returne
 class _DepthHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, min_depth, max_depth, flip):
-        ctx.bias_param = _HEAD_SLOT.pop(y.data_ptr(), None)
+        ent = _HEAD_SLOT.pop(y.data_ptr(), None)
+        ctx.bias_param = ent[0] if (ent is not None and ent[1]() is y) else None
         B, H, W, ld = y.shape
         depth = torch.empty(B, 1, H, W, device=y.device, dtype=torch.float32)
         L.check(L.lib().sde_depth_head_fwd(L.ptr(y.contiguous()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype), L.ptr(depth), L.stream()),
@@ -738,8 +744,8 @@ class _DepthHead(torch.autograd.Function):
             part = torch.empty(lib.sde_depth_head_bias_blocks(B, H, W), device=y.device)
             L.check(lib.sde_depth_head_bwd_bias(L.ptr(y), L.ptr(ddepth.contiguous().float()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype),
                                                 L.ptr(dy), L.ptr(part), L.ptr(bslot), 1, L.stream()), "sde_depth_head_bwd_bias")
-            if len(_HEAD_DONE) > 64:
-                _HEAD_DONE.clear()
+            global HEAD_BIAS_HITS
+            HEAD_BIAS_HITS += 1
             _HEAD_DONE[dy.data_ptr()] = id(ctx.bias_param)
         else:
             L.check(lib.sde_depth_head_bwd(L.ptr(y), L.ptr(ddepth.contiguous().float()), B, H, W, ld, min_depth, max_depth, int(flip), dtype_code(y.dtype),

@@ -304,8 +304,10 @@ def test_head_bias_gradient_from_the_depth_head_backward():
         try:
             model = build("SupDepthModel", 18, sd, "bf16").train()
             tr = supervised_trainer(model, make_cfg("SupDepthModel", 18, "bf16"))
+            hits = HN.HEAD_BIAS_HITS
             tr.step(clone_batch(batch))
             torch.cuda.synchronize()
+            assert HN.HEAD_BIAS_HITS - hits == (4 if fused else 0), "the four disparity heads must take the fused path exactly when it is on"
             names = [n for n, p in model.named_parameters() if n.endswith("conv.bias") and p.numel() == 1]
             res.append((tr.gflat.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if n in names}))
         finally:
