@@ -48,6 +48,30 @@ def test_python_binding_covers_header():
     L.lib()   # loads + binds argtypes; raises if a prototype names a symbol the .so lacks
 
 
+def declared_arity():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    out = {}
+    for name, params in re.findall(r"\b(sde_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        params = params.strip()
+        out[name] = 0 if params in ("", "void") else params.count(",") + 1
+    return out
+
+
+def test_python_prototypes_have_the_declared_number_of_arguments():
+    """A ctypes prototype with one argument too few or too many still binds and only fails (or corrupts the call) on the GPU: compare every
+    prototype's length with the parameter list of its declaration in include/sde_hip.h."""
+    from simpledepthestimation_amd.hip import lib as L
+    import simpledepthestimation_amd.hip.photometric  # noqa: F401
+    import simpledepthestimation_amd.hip.nn  # noqa: F401
+    import simpledepthestimation_amd.hip.evaluation  # noqa: F401
+    arity = declared_arity()
+    assert len(arity) >= 60, len(arity)
+    bad = {n: (len(L._PROTOS[n][0]), k) for n, k in arity.items() if n in L._PROTOS and len(L._PROTOS[n][0]) != k}
+    assert not bad, f"(prototype arguments, declared parameters) differ for: {bad}"
+
+
 def test_error_path_without_gpu(built):
     built.sde_last_error.restype = ctypes.c_char_p
     built.sde_resize.restype = ctypes.c_int
