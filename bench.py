@@ -66,34 +66,52 @@ def build(args, device):
     return cfg, model, trainer
 
 
-def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50"):
-    """Event-instrumented eager steps of the same workload: per GEMM launch (kind, tile variant) duration and algorithmic FLOPs."""
+def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50", step_ms=None):
+    """Event-instrumented eager steps of the same workload: per GEMM launch (kind, tile variant) duration and algorithmic FLOPs.
+
+    Every eager step issues the same launches in the same order, so a launch is identified by its index inside the step and its duration is
+    the MINIMUM over the `steps` instrumented steps (>= 4): an event pair also times whatever the host did between its launches, and one
+    host hiccup inside one pair used to poison a two-step sum (BENCH_r02: 7.68 ms "inside" a 6.73 ms step).  The line is flagged
+    `roofline_suspect` when it still contradicts the timed region."""
     from simpledepthestimation_amd.hip import lib as L
+    steps = max(4, steps)
     def one():
         trainer._fwd_bwd(batch)
         if trainer._cut is not None:
             trainer._backward_rest()
     one()                                        # eager warm-up (the timed region may have run under graph replay)
     torch.cuda.synchronize()
-    L.PROFILE, L.PROFILE_REPEAT = [], 6          # each GEMM launch six times back to back between its two events (lib.timed)
+    per_step = []
     for _ in range(steps):
+        L.PROFILE, L.PROFILE_REPEAT = [], 6      # each GEMM launch six times back to back between its two events (lib.timed)
         one()
-    torch.cuda.synchronize()
-    recs, L.PROFILE, L.PROFILE_REPEAT = L.PROFILE, None, 1
-    fam = {}
+        torch.cuda.synchronize()
+        per_step.append([(kind, work, variant, e0.elapsed_time(e1) / rep, meta) for kind, work, variant, e0, e1, meta, rep in L.PROFILE])
+    L.PROFILE, L.PROFILE_REPEAT = None, 1
+    n = len(per_step[0])
+    same = all(len(s) == n and all(a[:3] == b[:3] for a, b in zip(s, per_step[0])) for s in per_step)
+    if same:                                     # (kind, work, variant, min ms, median ms, meta) per launch of ONE step
+        recs = []
+        for i in range(n):
+            ds = sorted(s[i][3] for s in per_step)
+            recs.append((per_step[0][i][0], per_step[0][i][1], per_step[0][i][2], ds[0], ds[len(ds) // 2], per_step[0][i][4]))
+    else:                                        # launch sequences differ between steps (not expected): fall back to the last step as it is
+        recs = [(k, w, v, ms, ms, m) for k, w, v, ms, m in per_step[-1]]
     if os.environ.get("SDE_BENCH_LAYER_DUMP"):
         with open(os.environ["SDE_BENCH_LAYER_DUMP"], "w") as f:
             f.write("kind,variant,M,N,K,k,stride,mode,splits,us,tflops,unique_GBps\n")
-            for kind, flops, variant, e0, e1, meta, rep in recs[:len(recs) // steps]:
-                us = e0.elapsed_time(e1) * 1e3 / rep
+            for kind, flops, variant, ms, _med, meta in recs:
+                if kind.startswith("photo"):
+                    continue
+                us = ms * 1e3
                 m = meta or {}
                 f.write(f"{kind},{variant},{m.get('M')},{m.get('N')},{m.get('K')},{m.get('k')},{m.get('s')},{m.get('mode')},{m.get('splits', '')},"
                         f"{us:.1f},{flops / us / 1e6:.1f},{m.get('bytes', 0) / us / 1e3:.0f}\n")
     photo = {}
-    for kind, nbytes, variant, e0, e1, meta, _rep in recs:
+    for kind, nbytes, variant, ms, _med, meta in recs:
         if kind.startswith("photo"):
             f = photo.setdefault((kind, meta["h"], meta["w"]), {"ms": 0.0, "bytes": 0.0, "launches": 0})
-            f["ms"] += e0.elapsed_time(e1); f["bytes"] += nbytes; f["launches"] += 1
+            f["ms"] += ms; f["bytes"] += nbytes; f["launches"] += 1
     recs = [r for r in recs if not r[0].startswith("photo")]
     hbm = None
     if photo:
@@ -105,17 +123,22 @@ def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50"):
                "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                "all": {f"{k[0]}:{k[1]}x{k[2]}": {"us": round(x["ms"] * 1e3 / x["launches"], 2), "GBps": round(x["bytes"] / (x["ms"] * 1e-3) / 1e9, 1)}
                        for k, x in sorted(photo.items(), key=lambda kv: -kv[0][1])}}
-    for kind, flops, variant, e0, e1, _meta, rep in recs:
-        key = ("igemm" if kind.startswith("igemm") else kind, variant)
-        f = fam.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
-        f["ms"] += e0.elapsed_time(e1) / rep; f["flops"] += flops; f["launches"] += 1
-    dom_key = max(fam, key=lambda k: fam[k]["ms"])
-    dom = fam[dom_key]
+    fam = {}
     peak = MFMA_PEAK_TFLOPS[dtype]
+    roof_ms = 0.0                                # sum over launches of the roofline time: max(FLOPs / MFMA peak, algorithmic bytes / HBM peak)
+    for kind, flops, variant, ms, med, meta in recs:
+        key = ("igemm" if kind.startswith("igemm") else kind, variant)
+        f = fam.setdefault(key, {"ms": 0.0, "med": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
+        f["ms"] += ms; f["med"] += med; f["flops"] += flops; f["launches"] += 1; f["bytes"] += (meta or {}).get("bytes", 0)
+        if flops > 0:
+            roof_ms += max(flops / (peak * 1e12), (meta or {}).get("bytes", 0) / (HBM_PEAK_GBPS * 1e9)) * 1e3
+    gemm = {k: v for k, v in fam.items() if v["flops"] > 0}
+    dom_key = max(gemm, key=lambda k: gemm[k]["ms"])
+    dom = gemm[dom_key]
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    tot_ms = sum(f["ms"] for f in fam.values()); tot_fl = sum(f["flops"] for f in fam.values())
+    tot_ms = sum(f["ms"] for f in gemm.values()); tot_fl = sum(f["flops"] for f in gemm.values())
     if dom_key[0] != "igemm":
-        name = "wgrad_kernel<bf16,64x128>" if dtype == "bf16" else "wgrad_kernel<f32>"
+        name = "wgrad_dma_kernel / wgrad_kernel<16-bit,64x128>" if dtype != "fp32" else "wgrad_kernel<f32>"
     elif dom_key[1] >= 7000000:
         name = f"pgemm_kernel<{dtype},{(dom_key[1] - 7000000) // 1000}x{dom_key[1] % 1000}> (persistent LDS-DMA GEMM)"
     elif dom_key[1] >= 3000000:
@@ -123,13 +146,32 @@ def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50"):
     else:
         name = f"igemm_kernel<{dtype},{dom_key[1] // 1000}x{dom_key[1] % 1000}>"
     traffic, traffic_src = pmc_traffic(dom_key, dtype) if workload == "sup_r50" else (None, None)      # the committed counter passes are of that workload
-    return hbm, {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_source": traffic_src,
-            "kernel": name, "launches_per_step": dom["launches"] // steps, "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
-            "gemm_flops_per_step": tot_fl / steps, "gemm_ms_per_step": round(tot_ms / steps, 3),
-            "all_gemm_achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-            "families": {f"{k[0]}:{k[1]}": {"ms_per_step": round(v["ms"] / steps, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                            "launches_per_step": v["launches"] // steps} for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}}
+    out = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+           "traffic_source": traffic_src,
+           "kernel": name, "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+           "median_launch_us": round(dom["med"] * 1e3 / dom["launches"], 2),
+           "algorithmic_GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+           "timing": f"per launch: min over {steps} instrumented eager steps of (event pair around 6 back-to-back launches) / 6",
+           "gemm_flops_per_step": tot_fl, "gemm_ms_per_step": round(tot_ms, 3),
+           "all_gemm_achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+           # fraction of the per-launch roofline (each launch against the roof that binds IT: MFMA peak or HBM peak on its algorithmic bytes)
+           "all_gemm_attainable_frac": round(roof_ms / tot_ms, 4),
+           "families": {f"{k[0]}:{k[1]}": {"ms_per_step": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                           "launches_per_step": v["launches"]} for k, v in sorted(gemm.items(), key=lambda kv: -kv[1]["ms"])}}
+    # sanity guards: a GEMM family cannot take longer than the whole timed step, and the median must agree with the minimum
+    suspect = []
+    if step_ms is not None and any(v["ms"] > step_ms for v in gemm.values()):
+        suspect.append("a family's ms_per_step exceeds ms_per_step of the timed region")
+    if step_ms is not None and tot_ms > 2.0 * step_ms:
+        suspect.append("gemm_ms_per_step exceeds twice the timed step (the serial kernel sum is ~1.4x the two-queue step)")
+    if dom["med"] > 1.25 * dom["ms"]:
+        suspect.append("median launch duration of the dominant family is > 1.25x its minimum")
+    if not same:
+        suspect.append("launch sequences differed between instrumented steps")
+    out["roofline_suspect"] = bool(suspect)
+    if suspect:
+        out["roofline_suspect_why"] = suspect
+    return hbm, out
 
 
 def pmc_traffic(dom_key, dtype):
@@ -252,14 +294,36 @@ def self_launch(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0 or "")
+    # poll every rank: the first non-zero exit ends the run (the surviving ranks would otherwise sit in a collective until an outer timeout)
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            c = p.poll()
+            if c is not None and c != 0:
+                failed = (r, c)
+                break
+        time.sleep(0.2)
+    if failed is None:
+        failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    rd.join(timeout=10)
+    sys.stdout.write((buf[0] if buf else "") or "")
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write(f"bench.py: ranks failed (rank, exit code): {bad}\n")
-        sys.exit(1)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}; the other ranks were terminated\n")
+        sys.exit(failed[1] if 0 < failed[1] < 256 else 1)
 
 
 def main():
@@ -273,7 +337,7 @@ def main():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
-    ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline object (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="instrumented eager steps for the roofline object (0 = skip; at least 4 are run)")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = physical cores of one socket (SURVEY.md 8d)")
@@ -360,10 +424,13 @@ def main():
                "config": {"workload": f"{WORKLOADS[args.workload]['desc']}, {args.dtype} storage / fp32 accumulate, bs={args.batch}/GPU, "
                                       f"{args.height}x{args.width}, fwd+bwd+optimizer, random-init weights", "global_batch": args.batch * world,
                           "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "allreduce_overlap": bool(trainer.overlap)},
-               "rccl_ranks": world,
+               # the collective backend that actually ran ("rccl" = torch.distributed "nccl" on ROCm; "gloo" = the one-GPU rehearsal) and the
+               # number of physical devices the ranks were spread over
+               "backend": ("none" if world == 1 else {"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend())),
+               "rccl_ranks": (world if world > 1 and dist.get_backend() == "nccl" else 0), "devices": min(world, ndev),
                "final_losses": final}
         if args.profile_steps > 0:
-            hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype, args.workload)
+            hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype, args.workload, step_ms=ms)
             if hbm is not None:
                 out["roofline_photometric"] = hbm        # MonoDepth2 workloads: the HBM-bound warp+SSIM kernel next to the dominant GEMM
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only

@@ -312,11 +312,14 @@ int sde_conv3d_wgrad(const void* x, const void* dy, int B, int H, int W, int D, 
  * The descriptor is HOST memory and is copied into the kernel arguments (nothing to upload or keep alive): segment s covers
  * [seg_end[s-1], seg_end[s]) with its own lr / weight decay; bias_corr1/2 = (1 - beta1^t, 1 - beta2^t) (the step count lives on the host);
  * grad_scale multiplies g first (1/world_size after a sum all-reduce).
- * scale_state (optional, DEVICE float[3] = {loss_scale, found_inf, growth_tracker}): fp16 training with dynamic loss scaling, the
- * GradScaler of the reference's AMPTrainer (detectron2/engine/train_loop.py:L294-341) without its host sync: sde_grad_check raises
- * found_inf when any gradient is inf / nan, sde_adam_step divides the gradients by loss_scale and SKIPS the whole update when found_inf
- * is set, sde_loss_scale_update then backs the scale off (x backoff_factor) or counts towards growth (x growth_factor every
- * growth_interval clean steps) and clears found_inf.  The loss is multiplied by scale_state[0] on the device before backward. */
+ * scale_state (optional, DEVICE float[4] = {loss_scale, found_inf, growth_tracker, applied_steps}): fp16 training with dynamic loss
+ * scaling, the GradScaler of the reference's AMPTrainer (detectron2/engine/train_loop.py:L294-341) without its host sync:
+ * sde_grad_check raises found_inf when any gradient is inf / nan, sde_adam_step divides the gradients by loss_scale and SKIPS the whole
+ * update when found_inf is set, sde_loss_scale_update then backs the scale off (x backoff_factor) or counts towards growth (x
+ * growth_factor every growth_interval clean steps), counts the step in applied_steps when it was NOT skipped, and clears found_inf.
+ * With scale_state the optimizer's step count lives on the device (GradScaler.step skips optimizer.step(), so Adam's `step` does not
+ * advance on an overflow): the kernel ignores bias_corr1/2 and forms 1 - beta^(applied_steps + 1) itself from beta1_d / beta2_d.
+ * The loss is multiplied by scale_state[0] on the device before backward. */
 #define SDE_ADAM_MAX_SEG 8
 typedef struct sde_adam_desc {
     long seg_end[SDE_ADAM_MAX_SEG];
@@ -324,6 +327,7 @@ typedef struct sde_adam_desc {
     int32_t nseg, decoupled_wd;
     float beta1, beta2, eps, bias_corr1, bias_corr2, grad_scale;
     const float* scale_state;
+    double beta1_d, beta2_d;       /* the betas in double (device-side bias corrections of the scale_state path) */
 } sde_adam_desc;
 int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const sde_adam_desc* d, sde_stream_t stream);
 int sde_grad_check(const float* g, long n, float* scale_state, sde_stream_t stream);

@@ -1164,11 +1164,17 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                                                    const sde_adam_desc d) {
     float gs = d.grad_scale;
+    float bc1 = d.bias_corr1, bc2 = d.bias_corr2;
     if (d.scale_state) {
         if (d.scale_state[1] != 0.f) return;            // overflow in this step's gradients: skip (uniform over the grid)
         gs /= d.scale_state[0];
+        // the step count of the APPLIED updates lives on the device (a skipped step must not advance Adam's `step`): state[3], incremented
+        // by loss_scale_update_kernel behind this launch
+        const double t = (double)d.scale_state[3] + 1.0;
+        bc1 = (float)(1.0 - pow(d.beta1_d, t));
+        bc2 = (float)(1.0 - pow(d.beta2_d, t));
     }
-    const float beta1 = d.beta1, beta2 = d.beta2, rbc2 = 1.0f / sqrtf(d.bias_corr2);
+    const float beta1 = d.beta1, beta2 = d.beta2, rbc2 = 1.0f / sqrtf(bc2);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         int s = 0;
         while (s < d.nseg - 1 && i >= d.seg_end[s]) ++s;
@@ -1180,7 +1186,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
         const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
         m[i] = mi; v[i] = vi;
         const float denom = sqrtf(vi) * rbc2 + d.eps;
-        p[i] = pi - (lr / d.bias_corr1) * (mi / denom);
+        p[i] = pi - (lr / bc1) * (mi / denom);
     }
 }
 
@@ -1198,10 +1204,12 @@ __global__ void __launch_bounds__(256) grad_check_kernel(const float4* __restric
 }
 
 // GradScaler.update(): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and at growth_interval scale *= growth, tracker = 0.
+// state[3] counts the optimizer steps that were applied (not skipped).
 __global__ void loss_scale_update_kernel(float* __restrict__ state, float growth, float backoff, int interval) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (state[1] != 0.f) { state[0] *= backoff; state[2] = 0.f; }
     else {
+        state[3] += 1.f;                                 // one more optimizer step was applied (exact in fp32 up to 2^24 steps)
         const float t = state[2] + 1.f;
         if (t >= (float)interval) { state[0] *= growth; state[2] = 0.f; } else state[2] = t;
     }
@@ -1544,7 +1552,9 @@ int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const floa
 
 int sde_adam_step(float* p, const float* g, float* m, float* v, long n, const sde_adam_desc* d, sde_stream_t stream) {
     SDE_CHECK_ARG(p && g && m && v && d && n > 0, "sde_adam_step: null pointer");
-    SDE_CHECK_ARG(d->nseg > 0 && d->nseg <= SDE_ADAM_MAX_SEG && d->bias_corr1 > 0.f && d->bias_corr2 > 0.f, "sde_adam_step: bad descriptor (nseg %d)", d->nseg);
+    SDE_CHECK_ARG(d->nseg > 0 && d->nseg <= SDE_ADAM_MAX_SEG && (d->scale_state ? (d->beta1_d > 0.0 && d->beta1_d < 1.0 && d->beta2_d > 0.0 && d->beta2_d < 1.0)
+                                                                                  : (d->bias_corr1 > 0.f && d->bias_corr2 > 0.f)),
+                  "sde_adam_step: bad descriptor (nseg %d)", d->nseg);
     for (int i = 0; i < d->nseg; ++i)
         SDE_CHECK_ARG(d->seg_end[i] > (i ? d->seg_end[i - 1] : 0) && d->seg_end[i] <= n, "sde_adam_step: segment %d ends at %ld (n = %ld)", i, d->seg_end[i], n);
     SDE_CHECK_ARG(d->seg_end[d->nseg - 1] == n, "sde_adam_step: the segments must cover the buffer");

@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     constexpr int BIAS_BASE = D * STAGE_BYTES;          // bias ring [D][BN] floats behind the stage ring, indexed by the workgroup's item count
     constexpr int EN = BN > 64 ? 64 : BN, NCH = BN / EN;   // the epilogue stages EN output channels at a time
     constexpr int CST = EN * 2 + 16;                   // staging-tile row stride (bytes): 16-byte aligned, conflict-free 8-byte column writes
-    static_assert(BM * CST + PG_THREADS * 8 <= STAGE_BYTES, "the output staging tile must fit into one ring slot");
+    // staging tile + the per-tile BatchNorm reduction scratch red[PARTS][EN][2] floats behind it
+    static_assert(BM * CST + (PG_THREADS / (EN / 2)) * EN * 8 <= STAGE_BYTES, "the output staging tile and the statistics scratch must fit into one ring slot");
     static_assert(D >= 3 && (D - 2) * L <= 60, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [D][X: BM rows | W: BN rows], [D][BN] bias
 

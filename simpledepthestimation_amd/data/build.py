@@ -58,6 +58,37 @@ class InferenceSampler(data.Sampler):
         return len(self._local_indices)
 
 
+class TrainingSampler(data.Sampler):
+    """The reference's infinite training stream (samplers/distributed_sampler.py:L12-52): the concatenation of seeded permutations of
+    range(size) (or of range(size) itself without shuffling), of which rank r of w takes every w-th index starting at r.  The hook-driven
+    trainers (engine/train_loop.py: SimpleTrainer.run_step) pull `next(iterator)` for max_iter iterations and rely on it never ending.
+    seed=None: one seed for all ranks, drawn by rank 0 and broadcast (the role of comm.shared_random_seed)."""
+
+    def __init__(self, size, shuffle=True, seed=None):
+        if size <= 0:
+            raise ValueError("TrainingSampler needs a non-empty dataset")
+        self._size, self._shuffle = int(size), bool(shuffle)
+        self._world, self._rank = _world()
+        if seed is None:
+            seed = int(np.random.randint(2 ** 31))
+            if self._world > 1:
+                box = [seed]
+                dist.broadcast_object_list(box, src=0)
+                seed = int(box[0])
+        self._seed = int(seed)
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self._seed)
+        pos = self._rank                     # position of this rank's next index inside the current permutation
+        while True:
+            order = torch.randperm(self._size, generator=g) if self._shuffle else torch.arange(self._size)
+            while pos < self._size:
+                yield int(order[pos])
+                pos += self._world
+            pos -= self._size                # the stride carries over the seam between two permutations
+
+
 def _seed_worker(worker_id):
     import random
     seed = np.random.randint(2 ** 31) + worker_id
@@ -79,10 +110,13 @@ def build_detection_train_loader(cfg):
     assert isinstance(dataset, DatasetBase)
     name = cfg.DATALOADER.get("SAMPLER_TRAIN", "DDPSampler")
     logging.getLogger(__name__).info("Using training sampler %s", name)
-    if name != "DDPSampler":
-        raise ValueError(f"Unknown training sampler: {name}")      # the reference's TrainingSampler (infinite stream) has no user in the two projects
     world, rank = _world()
-    sampler = data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True)
+    if name == "TrainingSampler":            # build.py:L108-109: the infinite stream the hook-driven trainers iterate with a bare next()
+        sampler = TrainingSampler(len(dataset))
+    elif name == "DDPSampler":
+        sampler = data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True)
+    else:
+        raise ValueError(f"Unknown training sampler: {name}")
     return build_batch_data_loader(dataset, sampler, cfg.SOLVER.IMS_PER_BATCH, num_workers=cfg.DATALOADER.NUM_WORKERS)
 
 

@@ -110,7 +110,17 @@ class SimpleTrainer(TrainerBase):
         core = self.optimizer.model
         assert core.training, "[SimpleTrainer] model was changed to eval mode!"
         start = time.perf_counter()
-        data = next(self._data_loader_iter)
+        try:
+            data = next(self._data_loader_iter)
+        except StopIteration:
+            # a finite loader (SAMPLER_TRAIN "DDPSampler": one epoch per iterator) under the iteration-driven loop: start the next epoch.  The
+            # reference pairs this trainer with the infinite TrainingSampler (data/build.py:L108-109), which build_detection_train_loader also builds
+            self._epoch = getattr(self, "_epoch", 0) + 1
+            smp = getattr(getattr(self.data_loader, "batch_sampler", None), "sampler", None)
+            if hasattr(smp, "set_epoch"):
+                smp.set_epoch(self._epoch)
+            self._data_loader_iter = iter(self.data_loader)
+            data = next(self._data_loader_iter)
         data_time = time.perf_counter() - start
         loss_dict = self.optimizer.step(data)          # zero-grad + forward + backward (+ all-reduce) + Adam: one graph replay
         self._write_metrics(loss_dict, data_time)

@@ -113,7 +113,9 @@ class HipTrainer:
         # fp16 training (SOLVER.AMP, detectron2/engine/train_loop.py:L294-341): device-side GradScaler state {scale, found_inf, growth tracker}
         self.amp = bool(amp)
         self.growth_interval = int(growth_interval)
-        self.scale_state = torch.tensor([float(init_scale), 0.0, 0.0], device=dev, dtype=torch.float32) if self.amp else None
+        # + the count of APPLIED optimizer steps: GradScaler.step skips optimizer.step() on overflow, so Adam's `step` (bias corrections) must not
+        # advance then -- the Adam kernel derives its bias corrections from this device-side count, self.t only counts calls
+        self.scale_state = torch.tensor([float(init_scale), 0.0, 0.0, 0.0], device=dev, dtype=torch.float32) if self.amp else None
         # ---- gradient buckets for the all-reduce (contiguous slices of the flat gradient)
         per = max(1, int(bucket_mb * (1 << 20) / 4))
         self.buckets = [(s, min(total, s + per)) for s in range(0, total, per)]
@@ -159,14 +161,19 @@ class HipTrainer:
     # (DetectionCheckpointer(model, dir, optimizer=...) of projects/*/train.py): parameters are numbered group by group in
     # registration order; every parameter carries {'step', 'exp_avg', 'exp_avg_sq'}.  'param_names' is an addition that lets a load
     # match by name when the numbering differs (the reference's encoder group also holds the unused fc.weight / fc.bias).
+    def applied_steps(self):
+        """Optimizer steps actually applied: under AMP the device-side count (skipped overflow steps excluded; one host read), else self.t."""
+        return int(self.scale_state[3].item()) if self.amp else self.t
+
     def state_dict(self):
         state, groups, idx = {}, [], 0
+        t_applied = self.applied_steps()
         for g in self.groups:
             ids = []
             for _, p in g.named_params:
                 off = self._off[id(p)]
-                if self.t > 0:
-                    state[idx] = {"step": torch.tensor(float(self.t)), "exp_avg": flat_view(self.m, off, p).detach().cpu().contiguous().clone(),
+                if t_applied > 0:
+                    state[idx] = {"step": torch.tensor(float(t_applied)), "exp_avg": flat_view(self.m, off, p).detach().cpu().contiguous().clone(),
                                   "exp_avg_sq": flat_view(self.v, off, p).detach().cpu().contiguous().clone()}
                 ids.append(idx)
                 idx += 1
@@ -222,7 +229,9 @@ class HipTrainer:
             g.lr, g.weight_decay = float(tg.get("lr", g.lr)), float(tg.get("weight_decay", g.weight_decay))
         self.t = steps[0] if steps else 0
         if self.amp and "loss_scale" in sd:
-            self.scale_state.copy_(torch.tensor([float(sd["loss_scale"]), 0.0, float(sd.get("growth_tracker", 0.0))]))
+            self.scale_state.copy_(torch.tensor([float(sd["loss_scale"]), 0.0, float(sd.get("growth_tracker", 0.0)), float(self.t)]))
+        elif self.amp:
+            self.scale_state[3] = float(self.t)
 
     def _fwd_bwd(self, batch):
         self.gflat.zero_()

@@ -261,6 +261,14 @@ class _Conv2d(torch.autograd.Function):
         dz = dy
         # (the depth head's backward already summed this one-channel layer's bias gradient into its slot: nothing left to do in this step)
         head_did_bias = has_bias and act == ACT_NONE and dy1 is None and _HEAD_DONE.pop(dy.data_ptr(), None) == id(ctx.params[1])
+        if has_bias and not head_did_bias and id(ctx.params[1]) in _HEAD_DONE.values():
+            # depth_head's backward already accumulated its share of this bias gradient, but the gradient arriving here is not the tensor it
+            # returned: the logit has a second consumer and autograd summed the two -- adding the full column sum on top would count the
+            # head's share twice (the slot call accumulates)
+            for k in [k for k, v in _HEAD_DONE.items() if v == id(ctx.params[1])]:
+                del _HEAD_DONE[k]
+            raise L.SdeHipError("conv2d backward: the one-channel output feeding depth_head has a second consumer; the fused disparity-head bias "
+                                "gradient supports exactly one (set hip.nn.HEAD_BIAS_FUSED = False for such a graph)")
         if (act != ACT_NONE or has_bias or dy1 is not None) and not head_did_bias:
             nblk = lib.sde_reduce_num_blocks(M, ldy)
             part = torch.empty(nblk + REDUCE_ROWS, ldy, device=dev) if has_bias else None
@@ -862,12 +870,13 @@ ADAM_MAX_SEG = 8       # SDE_ADAM_MAX_SEG
 class AdamDesc(Structure):
     _fields_ = [("seg_end", c_long * ADAM_MAX_SEG), ("seg_lr", c_float * ADAM_MAX_SEG), ("seg_wd", c_float * ADAM_MAX_SEG), ("nseg", c_int32),
                 ("decoupled_wd", c_int32), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("bias_corr1", c_float), ("bias_corr2", c_float),
-                ("grad_scale", c_float), ("scale_state", c_void_p)]
+                ("grad_scale", c_float), ("scale_state", c_void_p), ("beta1_d", ctypes.c_double), ("beta2_d", ctypes.c_double)]
 
 
 def adam_step(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, decoupled_wd=False, scale_state=None):
     """seg_end / seg_lr / seg_wd: HOST sequences (one entry per segment); everything travels by value in the kernel arguments.
-    scale_state: optional device float[3] {loss_scale, found_inf, growth_tracker} (fp16 dynamic loss scaling)."""
+    scale_state: optional device float[4] {loss_scale, found_inf, growth_tracker, applied_steps} (fp16 dynamic loss scaling); with it the
+    kernel forms the bias corrections itself from the device-side count of APPLIED steps and `bias_corr` is ignored."""
     nseg = len(seg_end)
     if not (0 < nseg <= ADAM_MAX_SEG and len(seg_lr) == nseg and len(seg_wd) == nseg):
         raise L.SdeHipError(f"adam_step: {nseg} segments (at most {ADAM_MAX_SEG})")
@@ -877,6 +886,9 @@ def adam_step(p, g, m, v, seg_end, seg_lr, seg_wd, bias_corr, beta1=0.9, beta2=0
     d.nseg, d.decoupled_wd = nseg, int(bool(decoupled_wd))
     d.beta1, d.beta2, d.eps, d.bias_corr1, d.bias_corr2, d.grad_scale = beta1, beta2, eps, float(bias_corr[0]), float(bias_corr[1]), grad_scale
     d.scale_state = scale_state.data_ptr() if scale_state is not None else None
+    d.beta1_d, d.beta2_d = float(beta1), float(beta2)
+    if scale_state is not None and scale_state.numel() < 4:
+        raise L.SdeHipError("adam_step: scale_state must hold 4 floats {loss_scale, found_inf, growth_tracker, applied_steps}")
     L.check(L.lib().sde_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), ctypes.byref(d), L.stream()), "sde_adam_step")
 
 

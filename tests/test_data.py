@@ -220,6 +220,32 @@ def test_loaders_produce_the_batch_dict_contract(tree):
     pf = list(DevicePrefetcher(batches, "cpu"))
     assert len(pf) == len(batches) and torch.equal(pf[0]["img"], batches[0]["img"]) and torch.is_tensor(pf[0]["ctx_img"][0]) and pf[0]["flip"] == batches[0]["flip"]
     assert list(InferenceSampler(5)) == [0, 1, 2, 3, 4]
+    # SAMPLER_TRAIN "TrainingSampler" (data/build.py:L108-109 of the reference): the loader never ends -- more than one epoch of batches comes out
+    cfg.DATALOADER.SAMPLER_TRAIN = "TrainingSampler"
+    inf = iter(build_detection_train_loader(cfg))
+    many = [next(inf) for _ in range(7)]                # 7 batches of 2 from 5 samples: almost three epochs
+    assert all(m["img"].shape == (2, 3, 8, 32) for m in many)
+    cfg.DATALOADER.SAMPLER_TRAIN = "NoSuchSampler"
+    with pytest.raises(ValueError):
+        build_detection_train_loader(cfg)
+
+
+def test_training_sampler_is_the_strided_stream_of_seeded_permutations():
+    """samplers/distributed_sampler.py:L12-52: indices[rank::world] of shuffle(range(n)) + shuffle(range(n)) + ... drawn from ONE generator."""
+    import itertools
+    from simpledepthestimation_amd.data.build import TrainingSampler
+    n, seed = 7, 1234
+    g = torch.Generator(); g.manual_seed(seed)
+    stream = [int(i) for _ in range(6) for i in torch.randperm(n, generator=g)]
+    for world, rank in [(1, 0), (2, 0), (2, 1), (3, 2), (4, 1)]:
+        s = TrainingSampler(n, seed=seed)
+        s._world, s._rank = world, rank
+        got = list(itertools.islice(iter(s), 30 // world))
+        assert got == stream[rank::world][:len(got)], (world, rank)
+    s = TrainingSampler(4, shuffle=False, seed=0)
+    assert list(itertools.islice(iter(s), 10)) == [0, 1, 2, 3, 0, 1, 2, 3, 0, 1]
+    with pytest.raises(ValueError):
+        TrainingSampler(0)
 
 
 def test_pose_utils_numpy_and_torch_vs_reference(gd):

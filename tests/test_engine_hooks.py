@@ -119,6 +119,44 @@ def test_losses_stay_tensors_until_a_writer_reads_them():
     assert len(vals) == 4 and all(isinstance(v, float) and np.isfinite(v) for v, _ in vals)
 
 
+def test_simple_trainer_runs_past_one_epoch_of_a_finite_loader_and_over_the_infinite_sampler():
+    """SimpleTrainer.run_step pulls next(iterator) for max_iter iterations (train_loop.py:L227-247): a loader over the infinite TrainingSampler
+    never ends, and a finite (one epoch per iterator) loader is restarted at its end with the sampler's epoch advanced."""
+    import torch.utils.data as data
+    from simpledepthestimation_amd.data.build import TrainingSampler
+
+    class DS(data.Dataset):
+        def __len__(self):
+            return 5
+
+        def __getitem__(self, i):
+            return _batch(i)
+
+    class Smp(data.Sampler):
+        epoch = 0
+
+        def set_epoch(self, e):
+            self.epoch = e
+
+        def __iter__(self):
+            return iter(range(5))
+
+        def __len__(self):
+            return 5
+
+    model, opt = _setup()
+    smp = Smp()
+    finite = data.DataLoader(DS(), batch_sampler=data.BatchSampler(smp, 2, drop_last=True), collate_fn=lambda b: b[0])
+    tr = SimpleTrainer(model, finite, opt)
+    tr.train(0, 7)                                   # 2 batches per epoch: crosses three epoch boundaries
+    assert tr.iter == 7 and smp.epoch == 3
+    model, opt = _setup()
+    inf = data.DataLoader(DS(), batch_sampler=data.BatchSampler(TrainingSampler(5, seed=1), 2, drop_last=True), collate_fn=lambda b: b[0])
+    tr = SimpleTrainer(model, inf, opt)
+    tr.train(0, 9)
+    assert len(tr.storage.history("total_loss").values()) == 9
+
+
 def test_non_finite_loss_raises_at_the_next_write():
     model, opt = _setup()
     bad = _batch(1); bad["t"] = bad["t"] * float("nan")

@@ -319,6 +319,38 @@ def test_head_bias_gradient_from_the_depth_head_backward():
     assert int((others > 0).sum()) <= 4      # nothing but the four bias gradients may differ at all
 
 
+def test_head_bias_fused_path_refuses_a_second_consumer_of_the_logit():
+    """The fused disparity-head bias gradient owns the logit's gradient only when depth_head is the logit's ONLY consumer: with a second one autograd
+    hands the convolution a summed tensor, and adding its full column sum on top of the head's share would double count -- that raises instead."""
+    from simpledepthestimation_amd.hip import nn as HN
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 8, 16, 16, generator=g).bfloat16().to(dev)
+    w = (torch.randn(1, 16, 3, 3, generator=g) * 0.1).to(dev).requires_grad_(True)
+    b = torch.zeros(1, device=dev, requires_grad=True)
+    w.grad, b.grad = torch.zeros_like(w), torch.zeros_like(b)          # pre-allocated slots, as under HipTrainer
+
+    def run(second):
+        w.grad.zero_(); b.grad.zero_()
+        y = HN.conv2d(x, w, b, stride=1, pad=1, reflect=True)
+        d = HN.depth_head(y, 0.1, 80.0)
+        loss = d.sum() + (y.float().sum() if second else 0.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        return b.grad.clone()
+    hits = HN.HEAD_BIAS_HITS
+    one = run(False)
+    assert HN.HEAD_BIAS_HITS == hits + 1 and float(one.abs()) > 0
+    with pytest.raises(Exception, match="second consumer"):
+        run(True)
+    HN.HEAD_BIAS_FUSED = False
+    try:
+        two = run(True)                                   # the separate pass handles any graph: head share + 1 per pixel from the second consumer
+    finally:
+        HN.HEAD_BIAS_FUSED = True
+    assert abs(float(two) - float(one) - 2 * 8 * 16) < 1e-2 * abs(float(two))
+    assert torch.allclose(run(False), one)               # nothing stale is left behind by the refused backward
+
+
 def test_graph_replay_equals_eager():
     """The captured hipGraph step (zero-grad + batched weight pack + forward + backward) reproduces the eager step bit for bit."""
     from simpledepthestimation_amd.engine.trainer import supervised_trainer
@@ -617,3 +649,6 @@ def test_fp16_loss_scaling_steps_track_fp32_and_overflow_skips_the_step(arch, en
     # the scale travels with the optimizer state
     osd = t16.state_dict()
     assert osd["loss_scale"] == 0.5 * s0
+    # Adam's `step` counts the APPLIED updates only (GradScaler.step skips optimizer.step() on overflow), not the calls
+    assert t16.applied_steps() == sum(moved) and t16.t == len(moved) + 1
+    assert all(float(e["step"]) == sum(moved) for e in osd["state"].values())

@@ -463,6 +463,41 @@ def test_adam_step(NN, decoupled):
     assert (pd.cpu() - ref).abs().max().item() < 1e-6
 
 
+def test_adam_step_with_loss_scaling_keeps_torch_step_count_across_a_skipped_step(NN):
+    """torch.optim.AdamW driven the way GradScaler.step drives it (detectron2/engine/train_loop.py:L294-341): on an overflow optimizer.step()
+    is not called at all, so Adam's `step` -- and with it the bias corrections -- does not advance.  The fused path keeps the count of APPLIED
+    steps on the device (scale_state[3]); p, m, v after steps {ok, overflow, ok, ok} must equal torch's after three applied steps."""
+    g = torch.Generator().manual_seed(14)
+    n1, n2 = 1000, 777
+    p = torch.randn(n1 + n2, generator=g); gr = torch.randn(n1 + n2, generator=g)
+    pa, pb = p[:n1].clone().requires_grad_(True), p[n1:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{"params": [pa], "lr": 2e-4, "weight_decay": 1e-2}, {"params": [pb], "lr": 1e-4, "weight_decay": 0.0}], eps=1e-6)
+    pd, m, v = p.clone().to(dev), torch.zeros(n1 + n2, device=dev), torch.zeros(n1 + n2, device=dev)
+    state = torch.tensor([1024.0, 0.0, 0.0, 0.0], device=dev)
+    seg_end, seg_lr, seg_wd = [n1, n1 + n2], [2e-4, 1e-4], [1e-2, 0.0]
+    scales = []
+    for t, overflow in enumerate([False, True, False, False], start=1):
+        gt = gr * (1.0 + 0.1 * t)
+        scale = float(state[0])
+        gdev = (gt * scale).to(dev)                      # what backward of the scaled loss leaves in the flat gradient
+        if overflow:
+            gdev[5] = float("inf")
+        else:
+            pa.grad, pb.grad = gt[:n1].clone(), gt[n1:].clone()
+            opt.step()                                   # GradScaler.step: only without found_inf
+        NN.grad_check(gdev, state)
+        # a deliberately WRONG host-side bias correction: with scale_state the kernel must use its own count
+        NN.adam_step(pd, gdev, m, v, seg_end, seg_lr, seg_wd, (0.5, 0.5), eps=1e-6, decoupled_wd=True, scale_state=state)
+        NN.loss_scale_update(state, 2.0, 0.5, 1000)
+        scales.append(float(state[0]))
+    assert scales == [1024.0, 512.0, 512.0, 512.0] and float(state[3]) == 3.0 and float(state[1]) == 0.0
+    ref = torch.cat([pa.detach(), pb.detach()])
+    assert (pd.cpu() - ref).abs().max().item() < 1e-6
+    st = opt.state[pa]
+    assert float(st["step"]) == 3.0
+    assert (m[:n1].cpu() - st["exp_avg"]).abs().max().item() < 1e-6 and (v[:n1].cpu() - st["exp_avg_sq"]).abs().max().item() < 1e-6
+
+
 def test_full_size_conv_properties(NN):
     """BASELINE size (B=12, 48x160, 64->64 3x3, bf16): linearity in the input and agreement of a strided sub-sample with fp32 CPU."""
     g = torch.Generator().manual_seed(5)
