@@ -383,6 +383,8 @@ def main():
             k, v = kv.split("=")
             if k == "bn_fuse":                  # --opt bn_fuse=2 -> sde_bn_set_fuse(2)
                 L.lib().sde_bn_set_fuse(int(v))
+            elif k == "bnbwd":                  # --opt bnbwd=0 -> BatchNorm's backward reduce as its own pass everywhere (A/B)
+                HN.BNBWD_FUSED = bool(int(v))
             elif k == "head_bias":              # --opt head_bias=0 -> disparity-head bias gradients by the separate pass
                 HN.HEAD_BIAS_FUSED = bool(int(v))
             else:

@@ -179,6 +179,16 @@ int sde_conv_fwd(const sde_conv_desc* d, const void* w_packed, const float* bias
 size_t sde_conv_fwd_ws_bytes(const sde_conv_desc* d, int ldy);
 int sde_conv_fwd_ws(const sde_conv_desc* d, const void* w_packed, const float* bias, int act, void* y, int Cout, int ldy, float* stats, void* ws,
                     size_t ws_bytes, sde_stream_t stream);
+/* Data gradient of a stride-1 convolution whose INPUT was relu(BatchNorm(y_bn)) with no residual and no other consumer (torchvision Bottleneck:
+ * conv2 <- bn1, conv3 <- bn2; BasicBlock: conv2 <- bn1 -- detectron2/layers/resnet_encoder.py:L88-99 wraps those blocks): the GEMM is the one
+ * sde_conv_fwd runs for the same descriptor (d = the dgrad view: source dz, flipped operand), and its epilogue takes over the first pass of
+ * BatchNorm's backward: gm [M][ldy] = (fma(y_bn, scale, shift) > 0) * g is stored instead of g, and part [rows][Cout][2] receives the
+ * per-workgroup sums (sum gm, sum gm * xhat), xhat = (y_bn - mean) * rstd; bnp [4][Cout] = (mean, rstd, scale, shift) as sde_bn_finalize wrote it.
+ * sde_conv_dgrad_bnbwd_rows: rows of that slab, or 0 when the dispatcher has no fused form for this layer (fp32, split-K, stride 2, channel
+ * counts that are not multiples of 64, narrow layers): the caller then runs sde_conv_fwd and sde_bn_bwd.  Follow with sde_bn_bwd_from_part. */
+int sde_conv_dgrad_bnbwd_rows(const sde_conv_desc* d, int Cout, int ldy);
+int sde_conv_dgrad_bnbwd(const sde_conv_desc* d, const void* w_packed, void* gm, int Cout, int ldy, const void* bn_y, const float* bnp, float* part,
+                         sde_stream_t stream);
 int sde_conv_fwd_tiles_m(const sde_conv_desc* d, int ldy);
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy);
 /* Tuning / test knob: the LDS-halo 3x3 kernel is used when a launch has at least this many workgroups (default 192; 0 = whenever it
@@ -201,6 +211,8 @@ int sde_conv_set_halo_min_blocks(int min_blocks);
                                   kernel (csrc/conv_halo_small.hip) in the forward and data-gradient passes; 0: the generic kernel */
 #define SDE_OPT_WGRAD_DMA 9    /* 1 (default): layers with 64-channel-multiple inputs and outputs (zero padding, no concat) take the LDS-DMA weight-gradient
                                   kernel (csrc/wgrad_dma.hip); 0: the register-staged kernel */
+#define SDE_OPT_BNBWD_FUSE 10  /* 1 (default): sde_conv_dgrad_bnbwd_rows reports the layers whose data gradient can carry BatchNorm's backward reduction
+                                * in its epilogue; 0: it reports none (the separate bn_bwd_reduce pass runs everywhere: A/B, tests) */
 int sde_conv_set_option(int key, int value);
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).
@@ -259,6 +271,11 @@ int sde_reduce_num_blocks(long M, int C);
 int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const void* out, const void* y, const float* bnp, const float* gamma, int relu,
                long M, int C, int dtype, float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* gm, void* dy,
                sde_stream_t stream);
+/* The same backward with the reduce pass already done by the data-gradient GEMM that produced the incoming gradient (sde_conv_dgrad_bnbwd):
+ * gm [M,C] = relu'(bn(y)) * g as that GEMM stored it, part [rows + SDE_REDUCE_ROWS][C][2] = its per-workgroup (sum gm, sum gm * xhat).  Runs the
+ * finalize and apply passes only (one launch for rows <= 256 and C % 64 == 0, as sde_bn_bwd).  dy [M,C]; dgamma/dbeta [C] (+)=; coef [2][C]. */
+int sde_bn_bwd_from_part(const float* part, int rows, const void* gm, const void* y, const float* bnp, long M, int C, int dtype, float* coef,
+                         float* dgamma, float* dbeta, int accumulate_params, void* dy, sde_stream_t stream);
 
 /* nn.MaxPool2d(3, 2, 1) (resnet_encoder.py:L94).  idx: [B,OH,OW,C] u8 arg-max saved for backward. */
 int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* out, uint8_t* idx, sde_stream_t stream);

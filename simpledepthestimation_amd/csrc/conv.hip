@@ -653,6 +653,52 @@ __global__ void __launch_bounds__(NTHREADS, 2) halo3_kernel(IGemmP p) {
     __syncthreads();
     constexpr int G4 = BN / 4;
     const bool vec_ok = (p.ldy % 4) == 0;
+    if (p.bn_y) {
+        // BatchNorm-backward epilogue (IGemmP::bn_y): this tile of the data gradient g is masked with relu'(bn(y_bn)) -- the mask re-derived from
+        // y_bn exactly as bn_bwd_reduce does -- and stored; every thread keeps (sum gm, sum gm * xhat) of its 4 channels over its rows in
+        // registers, the 16 row groups are combined through the (then free) tile buffer.  Host: Cout % BN == 0, ldy == Cout.
+        static_assert(NTHREADS % G4 == 0, "a thread keeps one channel group");
+        const int c0 = (tid % G4) * 4, n = n0 + c0;
+        const float4 mean = *reinterpret_cast<const float4*>(p.bnp + n), rstd = *reinterpret_cast<const float4*>(p.bnp + p.Cout + n);
+        const float4 scl = *reinterpret_cast<const float4*>(p.bnp + 2 * p.Cout + n), shf = *reinterpret_cast<const float4*>(p.bnp + 3 * p.Cout + n);
+        const float mn[4] = {mean.x, mean.y, mean.z, mean.w}, rs[4] = {rstd.x, rstd.y, rstd.z, rstd.w};
+        const float sc[4] = {scl.x, scl.y, scl.z, scl.w}, sf[4] = {shf.x, shf.y, shf.z, shf.w};
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int id = tid; id < BM * G4; id += NTHREADS) {
+            const int row = id / G4;
+            const int oy = oy0 + row / HT_W, ox = ox0 + row % HT_W;
+            if (!(oy < g.OH && ox < g.OW)) continue;
+            const size_t off = ((size_t)(img * g.OH + oy) * g.OW + ox) * p.ldy + n;
+            const uint2 yr = *reinterpret_cast<const uint2*>((const T*)p.bn_y + off);
+            const T* yt = reinterpret_cast<const T*>(&yr);
+            const float4 q = *reinterpret_cast<const float4*>(&sC[row * (BN + CPAD) + c0]);
+            const float v[4] = {q.x, q.y, q.z, q.w};
+            T o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float yv = to_f32<T>(yt[e]);
+                o[e] = from_f32<T>(fmaf(yv, sc[e], sf[e]) > 0.f ? v[e] : 0.f);
+                const float t = to_f32<T>(o[e]);
+                a1[e] += t; a2[e] += t * ((yv - mn[e]) * rs[e]);
+            }
+            *reinterpret_cast<uint2*>((T*)p.y + off) = *reinterpret_cast<uint2*>(o);
+        }
+        __syncthreads();                               // every thread is done with the accumulator tile
+        constexpr int PARTS = NTHREADS / G4;
+        float* red = sC;                               // [PARTS][BN][2]
+        const int part = tid / G4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(part * BN + c0 + e) * 2] = a1[e]; red[(part * BN + c0 + e) * 2 + 1] = a2[e]; }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Cout) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) { a += red[(q * BN + tid) * 2]; b += red[(q * BN + tid) * 2 + 1]; }
+            p.stats[((size_t)tile_m * p.Cout + n0 + tid) * 2 + 0] = a;
+            p.stats[((size_t)tile_m * p.Cout + n0 + tid) * 2 + 1] = b;
+        }
+        return;
+    }
     for (int id = tid; id < BM * G4; id += NTHREADS) {
         const int row = id / G4, c0 = (id - row * G4) * 4;
         const int oy = oy0 + row / HT_W, ox = ox0 + row % HT_W, n = n0 + c0;
@@ -1383,6 +1429,7 @@ int fill_gather(const sde_conv_desc* d, Gather& g, const char* who) {
 // persistent LDS-DMA GEMM (pgemm.hip)
 namespace sdeconv {
 bool pgemm_applicable(const Gather& g, int dtype, int ldy);
+bool pgemm_bnbwd_ok(const Gather& g, int dtype, int ldy, int Cout, int depth);
 int pgemm_tile(long M, int ldy);
 int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s);
 int pgemm_stats_rows(const Gather& g, int ldy, int depth);
@@ -1451,6 +1498,7 @@ static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const flo
     p.w = w_packed; p.bias = bias; p.y = y; p.stats = stats; p.Cout = Cout; p.ldy = ldy; p.act = act;
     p.ksplit = 1; p.ws = nullptr;
     p.no_kfull = 0;
+    p.bn_y = nullptr; p.bnp = nullptr;
     const int S = ws ? pick_ksplit(p.g, d->dtype, ldy) : 1;
     if (S > 1) {
         SDE_CHECK_ARG(ws_bytes >= (size_t)S * p.g.M * ldy * sizeof(float), "sde_conv_fwd_ws: workspace too small (%zu bytes)", ws_bytes);
@@ -1497,6 +1545,45 @@ int sde_conv_fwd_ws(const sde_conv_desc* d, const void* w_packed, const float* b
 }
 
 static int gather_of(const sde_conv_desc* d, Gather& g) { return fill_gather(d, g, "sde_conv_fwd_tiles_m"); }
+
+int g_bnbwd_fuse = 1;       // SDE_OPT_BNBWD_FUSE
+
+// 1 = persistent GEMM, 2 = LDS-halo 3x3 kernel, 0 = this layer's data gradient runs on a kernel without the BatchNorm-backward epilogue
+static int bnbwd_kind(const Gather& g, int dtype, int ldy, int Cout) {
+    if (!g_bnbwd_fuse || !SDE_IS16(dtype) || ldy != Cout || Cout % 64 || g.mode != SDE_SRC_PLAIN || g.stride != 1 || g.reflect) return 0;
+    if (pick_ksplit(g, dtype, ldy) != 1) return 0;
+    if (use_chalo(g, dtype, ldy)) return 0;
+    if (use_pgemm(g, dtype, ldy)) return sdeconv::pgemm_bnbwd_ok(g, dtype, ldy, Cout, g_pgemm_depth) ? 1 : 0;
+    if (use_halo(g, dtype, ldy)) return halo_bn(g, ldy) == 64 ? 2 : 0;
+    return 0;
+}
+
+int sde_conv_dgrad_bnbwd_rows(const sde_conv_desc* d, int Cout, int ldy) {
+    Gather g;
+    if (!d || fill_gather(d, g, "sde_conv_dgrad_bnbwd_rows") != SDE_OK) return 0;
+    const int kind = bnbwd_kind(g, d->dtype, ldy, Cout);
+    if (kind == 1) return sdeconv::pgemm_stats_rows(g, ldy, g_pgemm_depth);
+    if (kind == 2) return halo_tiles_m(g);
+    return 0;
+}
+
+int sde_conv_dgrad_bnbwd(const sde_conv_desc* d, const void* w_packed, void* gm, int Cout, int ldy, const void* bn_y, const float* bnp, float* part,
+                         sde_stream_t stream) {
+    SDE_CHECK_ARG(d && w_packed && gm && bn_y && bnp && part, "sde_conv_dgrad_bnbwd: null pointer");
+    IGemmP p;
+    int rc = fill_gather(d, p.g, "sde_conv_dgrad_bnbwd");
+    if (rc) return rc;
+    const int kind = bnbwd_kind(p.g, d->dtype, ldy, Cout);
+    SDE_CHECK_ARG(kind != 0, "sde_conv_dgrad_bnbwd: this layer has no fused form (ask sde_conv_dgrad_bnbwd_rows first)");
+    p.w = w_packed; p.bias = nullptr; p.y = gm; p.stats = part; p.Cout = Cout; p.ldy = ldy; p.act = SDE_ACT_NONE;
+    p.ksplit = 1; p.ws = nullptr; p.no_kfull = 0;
+    p.bn_y = bn_y; p.bnp = bnp;
+    if (kind == 1) sdeconv::pgemm_run(p, d->dtype, g_pgemm_depth, (hipStream_t)stream);
+    else if (d->dtype == SDE_BF16) dispatch_halo<bf16_t>(p, (hipStream_t)stream);
+    else dispatch_halo<half_t>(p, (hipStream_t)stream);
+    SDE_CHECK_LAUNCH("sde_conv_dgrad_bnbwd");
+    return SDE_OK;
+}
 
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
     Gather g;
@@ -1689,7 +1776,7 @@ int sde_conv_set_option(int key, int value) {
         return old;
     }
     int* slot = key == SDE_OPT_PGEMM ? &g_use_pgemm : key == SDE_OPT_PGEMM_DEPTH ? &g_pgemm_depth : key == SDE_OPT_PGEMM_3X3 ? &g_pgemm_3x3 :
-                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : key == SDE_OPT_CONV_SMALL ? &g_conv_small : key == SDE_OPT_WGRAD_DMA ? &g_wgrad_dma : nullptr;
+                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : key == SDE_OPT_CONV_SMALL ? &g_conv_small : key == SDE_OPT_WGRAD_DMA ? &g_wgrad_dma : key == SDE_OPT_BNBWD_FUSE ? &g_bnbwd_fuse : nullptr;
     SDE_CHECK_ARG(slot, "sde_conv_set_option: unknown key %d", key);
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_DEPTH || value == 3 || value == 4, "sde_conv_set_option: ring depth must be 3 or 4");
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_TILE || value == 0 || value == 64064 || value == 128064 || value == 128128, "sde_conv_set_option: bad tile %d", value);

@@ -46,6 +46,12 @@ struct IGemmP {
     int ksplit;           // > 1: the K loop is cut into ksplit ranges, each workgroup writes its raw fp32 tile to ws[split][M][ldy]
     float* ws;            //      and splitk_finish_kernel sums them in a fixed order and applies bias / activation / statistics
     int no_kfull;         // experiment switch (SDE_NO_KFULL): disable the scalar-offset 1x1 loader
+    // BatchNorm-backward epilogue (sde_conv_dgrad_bnbwd): this GEMM is the data gradient that produces g = dL/d relu(bn(y_bn)).  The epilogue
+    // masks it with the ReLU mask re-derived from y_bn and the BatchNorm parameters (fma(y, scale, shift) > 0, the expression bn_apply
+    // evaluates), stores gm = mask * g, and writes the reduction of BatchNorm's backward -- (sum gm, sum gm * xhat) per channel -- into the
+    // `stats` slab in place of (sum y, sum y^2): the separate bn_bwd_reduce pass over g and y_bn disappears.
+    const void* bn_y;     // [M][ldy] raw convolution output the BatchNorm normalised (same layout as this GEMM's output), or null
+    const float* bnp;     // [4][Cout]: mean, rstd, scale, shift
 };
 
 

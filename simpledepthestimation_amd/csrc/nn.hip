@@ -1397,6 +1397,40 @@ int sde_bn_bwd(const void* dout, const void* dout1, const void* dout2, const voi
     return SDE_OK;
 }
 
+int sde_bn_bwd_from_part(const float* part, int rows, const void* gm, const void* y, const float* bnp, long M, int C, int dtype, float* coef,
+                         float* dgamma, float* dbeta, int accumulate_params, void* dy, sde_stream_t stream) {
+    const int V = SDE_IS16(dtype) ? 8 : 4;
+    SDE_CHECK_ARG(part && gm && y && bnp && coef && dgamma && dbeta && dy && rows > 0 && M > 0 && C > 0 && C % V == 0, "sde_bn_bwd_from_part: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (g_bn_fuse && SDE_IS16(dtype) && C % 64 == 0 && rows <= BNFA_MAX_ROWS) {       // short slab: finalize + apply in one launch
+        const int strips = C / 64;
+        long chunks = (1024 + strips - 1) / strips;
+        long rpw = (M + chunks - 1) / chunks;
+        rpw = (rpw + 31) / 32 * 32;
+        chunks = (M + rpw - 1) / rpw;
+        const dim3 grid((unsigned)strips, (unsigned)chunks);
+        if (dtype == SDE_BF16)
+            hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<bf16_t>, grid, dim3(256), 0, s, part, rows, C, (float)M, dgamma, dbeta, accumulate_params, (const bf16_t*)gm,
+                               (const bf16_t*)y, bnp, M, rpw, (bf16_t*)dy);
+        else
+            hipLaunchKernelGGL(bn_bwd_finalize_apply_kernel<half_t>, grid, dim3(256), 0, s, part, rows, C, (float)M, dgamma, dbeta, accumulate_params, (const half_t*)gm,
+                               (const half_t*)y, bnp, M, rpw, (half_t*)dy);
+        SDE_CHECK_LAUNCH("sde_bn_bwd_from_part/finalize+apply");
+        return SDE_OK;
+    }
+    int r = rows;
+    const float* src = pre_reduce(part, r, 2 * C, s);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(sde_cdiv(C, 8)), dim3(SLAB_T), 0, s, src, r, C, (float)M, dgamma, dbeta, accumulate_params, coef);
+    SDE_CHECK_LAUNCH("sde_bn_bwd_from_part/finalize");
+    const int nb = grid_for(M * (C / V));
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)gm, (const float*)y, bnp, coef, M, C, (float*)dy),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)gm, (const bf16_t*)y, bnp, coef, M, C, (bf16_t*)dy),
+               hipLaunchKernelGGL(bn_bwd_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)gm, (const half_t*)y, bnp, coef, M, C, (half_t*)dy));
+    SDE_CHECK_LAUNCH("sde_bn_bwd_from_part/apply");
+    return SDE_OK;
+}
+
 int sde_maxpool_fwd(const void* x, int B, int H, int W, int C, int dtype, void* out, uint8_t* idx, sde_stream_t stream) {
     const int V = SDE_IS16(dtype) ? 8 : 4;
     SDE_CHECK_ARG(x && out && idx && B > 0 && H > 1 && W > 1 && C % V == 0, "sde_maxpool_fwd: bad argument");

@@ -160,7 +160,11 @@ __device__ __forceinline__ PGWork pg_next(const PGemmP& q, const PGWork& wk, int
     return pg_work<BM, BN, SRC>(q, w_next);
 }
 
-template <typename T16, int BM, int BN, int SRC, int D>
+__device__ __forceinline__ void pg_lds_store4(unsigned addr, unsigned a) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(a) : "memory"); }
+
+// BNB: BatchNorm-backward epilogue (IGemmP::bn_y / bnp): the output tile is masked with relu'(bn(y_bn)) and the statistics slab receives
+// (sum gm, sum gm * xhat) instead of (sum y, sum y^2).
+template <typename T16, int BM, int BN, int SRC, int D, bool BNB = false>
 __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     typedef typename PgType<T16>::frag frag_t;
     constexpr int WTM = BM / 2, WTN = BN / 2;          // 2 x 2 waves
@@ -467,6 +471,57 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             // which makes hipcc's waitcnt pass alias-check it against the LDS-DMA writes in flight and emit s_waitcnt vmcnt(0) in front of it.
             constexpr int G8 = EN / 8;                                      // 16-byte groups per staged row
             const int nc0 = n0 + ch * EN;
+            if constexpr (BNB) {
+                // BatchNorm-backward pass over the staged gradient tile, in the statistics pass's thread mapping (channel pair c2, row set part):
+                // read g (LDS) and y_bn (global, the same [m][n] addresses as the output), mask, write gm back into the tile for the store loop
+                // below, accumulate (sum gm, sum gm * xhat).  The host guarantees Cout % 64 == 0 and ldy == Cout (no ragged channels).
+                constexpr int PARTS = PG_THREADS / (EN / 2);
+                constexpr int RPT = BM / PARTS;                             // rows per thread
+                const int c2 = tid % (EN / 2), part = tid / (EN / 2);
+                const int cg = nc0 + 2 * c2;
+                const int rows = (g.M - m0) < BM ? (g.M - m0) : BM;
+                // Every global load of this pass goes through inline asm and is waited for by hand: a VGPR-destination load the compiler can SEE
+                // makes its waitcnt pass track vector-memory events in this loop nest, and it then orders the K loop's LDS reads behind the
+                // LDS-DMA in flight (s_waitcnt vmcnt(0) per stage: the ring would run empty).  In-order vmcnt: waiting for these loads also
+                // waits for the (older) stages of the next tile already in flight, which the K loop would wait for next anyway.
+                const float* bp = p.bnp + cg;
+                pg_f32x2 mean, rstd, sc, sf;
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mean) : "v"(bp) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rstd) : "v"(bp + p.Cout) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sc) : "v"(bp + 2 * p.Cout) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sf) : "v"(bp + 3 * p.Cout) : "memory");
+                const unsigned char* yb = reinterpret_cast<const unsigned char*>(p.bn_y) + ((size_t)m0 * p.ldy + cg) * 2;
+                unsigned yraw[RPT];
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const int r = part + k * PARTS;
+                    const unsigned char* src = yb + (size_t)(r < rows ? r : 0) * p.ldy * 2;       // (rows >= 1; the value of an out-of-range row is not used)
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(yraw[k]) : "v"(src) : "memory");
+                }
+                static_assert(RPT == 8, "the wait below names eight loads");
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(mean), "+v"(rstd), "+v"(sc), "+v"(sf), "+v"(yraw[0]), "+v"(yraw[1]), "+v"(yraw[2]), "+v"(yraw[3]), "+v"(yraw[4]), "+v"(yraw[5]),
+                               "+v"(yraw[6]), "+v"(yraw[7])
+                             :: "memory");
+                pg_f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const int r = part + k * PARTS;
+                    if (r < rows) {
+                        pg_f32x2 t = PgType<T16>::unpack2(*reinterpret_cast<const unsigned*>(sC + r * CST + c2 * 4));
+                        const pg_f32x2 yv = PgType<T16>::unpack2(yraw[k]);
+                        t[0] = fmaf(yv[0], sc[0], sf[0]) > 0.f ? t[0] : 0.f;
+                        t[1] = fmaf(yv[1], sc[1], sf[1]) > 0.f ? t[1] : 0.f;
+                        pg_lds_store4(sC_a + r * CST + c2 * 4, PgType<T16>::pack2(t[0], t[1]));
+                        s1 += t;
+                        s2 += t * ((yv - mean) * rstd);
+                    }
+                }
+                if (q.stats_acc) { st1[ch] += s1; st2[ch] += s2; st_n0 = n0; }
+                else pg_lds_store16(sC_a + BM * CST + (part * EN + 2 * c2) * 8, s1[0], s2[0], s1[1], s2[1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             if (SRC == SRC_ZEROINS_ZERO) {       // row m of the class -> output pixel (2 ci + ih0, 2 cj + iw0)
                 const PGClass k = pg_class(g, wk.cls);
 #pragma unroll
@@ -502,6 +557,20 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
                     *reinterpret_cast<u32x4*>((unsigned char*)p.y + ((size_t)m * p.ldy + n) * 2) = *reinterpret_cast<const u32x4*>(sC + row * CST + c8 * 16);
             }
             }
+            if constexpr (BNB) {
+                constexpr int PARTS = PG_THREADS / (EN / 2);
+                const float* red = reinterpret_cast<const float*>(sC + BM * CST);       // [PARTS][EN][2], written by the pass above
+                if (!q.stats_acc && tid < EN && nc0 + tid < p.Cout) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int z = 0; z < PARTS; ++z) {
+                        const pg_f32x2 v = *reinterpret_cast<const pg_f32x2*>(red + (z * EN + tid) * 2);
+                        a += v[0]; b += v[1];
+                    }
+                    p.stats[((size_t)wk.tile_m * p.Cout + nc0 + tid) * 2 + 0] = a;
+                    p.stats[((size_t)wk.tile_m * p.Cout + nc0 + tid) * 2 + 1] = b;
+                }
+            } else
             if (p.stats) {
                 // per-tile column sums of y and y^2 (of the rounded values) over the valid rows: PARTS interleaved row sets per column
                 // thread = (channel pair tid % (EN/2), row set tid / (EN/2)): one 4-byte LDS read per row, packed fp32 math
@@ -575,12 +644,12 @@ static bool pg_stats_acc(int tiles_n, int tiles_mn, int ksplit, int src, int BM,
     return ksplit == 1 && src != SRC_ZEROINS_ZERO && tiles_mn > grid && (grid >> 3) % tiles_n == 0;
 }
 
-template <typename T16, int BM, int BN, int SRC, int D>
+template <typename T16, int BM, int BN, int SRC, int D, bool BNB = false>
 static int pg_launch(const PGemmP& q, hipStream_t s) {
     constexpr int lds = D * ((BM + BN) * PG_STAGE_K_BYTES + BN * 4);      // stage ring + bias ring
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm_kernel<T16, BM, BN, SRC, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm_kernel<T16, BM, BN, SRC, D, BNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     int grid = pg_grid_max(BM, BN, D);
@@ -588,7 +657,7 @@ static int pg_launch(const PGemmP& q, hipStream_t s) {
     PGemmP qq = q;
     qq.fast = (q.p.ksplit == 1 && SRC != SRC_ZEROINS_ZERO && grid % 8 == 0 && (grid >> 3) % q.tiles_n == 0) ? 1 : 0;
     qq.tm_step = qq.fast ? (grid >> 3) / q.tiles_n : 0;
-    hipLaunchKernelGGL((pgemm_kernel<T16, BM, BN, SRC, D>), dim3(grid), dim3(PG_THREADS), lds, s, qq);
+    hipLaunchKernelGGL((pgemm_kernel<T16, BM, BN, SRC, D, BNB>), dim3(grid), dim3(PG_THREADS), lds, s, qq);
     return 0;
 }
 
@@ -635,8 +704,17 @@ int pgemm_tile(long M, int ldy) {
 
 static int pg_depth(int tile, int depth) { return tile == 128128 || depth == 3 ? 3 : 4; }      // the ring depth pgemm_run_t instantiates
 
+// The layers whose BatchNorm-backward reduction can ride in this kernel's epilogue: 64x64 tiles, ring depth 3, one K range, 1x1 or zero-padded
+// k x k stride-1 sources, full 64-channel output tiles.
+bool pgemm_bnbwd_ok(const Gather& g, int dtype, int ldy, int Cout, int depth) {
+    if (!pgemm_applicable(g, dtype, ldy) || pgemm_tile(g.M, ldy) != 64064 || depth != 3) return false;
+    const int src = pgemm_src_kind(g);
+    return (src == SRC_1X1 || src == SRC_PLAIN_ZERO) && g.stride == 1 && Cout % 64 == 0 && ldy == Cout;
+}
+
 template <typename T16>
 static int pgemm_run_t(const PGemmP& q, int tile, int src, int depth, hipStream_t s) {
+    if (q.p.bn_y) return src == SRC_1X1 ? pg_launch<T16, 64, 64, SRC_1X1, 3, true>(q, s) : pg_launch<T16, 64, 64, SRC_PLAIN_ZERO, 3, true>(q, s);
     if (tile == 128128) return pg_dispatch_src<T16, 128, 128, 3>(q, src, s);
     if (tile == 128064) return depth == 3 ? pg_dispatch_src<T16, 128, 64, 3>(q, src, s) : pg_dispatch_src<T16, 128, 64, 4>(q, src, s);
     return depth == 3 ? pg_dispatch_src<T16, 64, 64, 3>(q, src, s) : pg_dispatch_src<T16, 64, 64, 4>(q, src, s);

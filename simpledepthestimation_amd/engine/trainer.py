@@ -136,8 +136,10 @@ class HipTrainer:
                 owner._grad_cut = self._cut
         if self._cut is None:
             self.overlap = False
-        # MonoDepth2: PoseNet on the auxiliary stream underneath the depth network (hip/lib.py: POSE_STREAM); the two-phase backward keeps one stream
-        self.pose_stream = bool(pose_stream) and self._cut is None and adam_fn is None
+        # MonoDepth2: PoseNet on the auxiliary stream underneath the depth network (hip/lib.py: POSE_STREAM).  Under the two-phase backward of the
+        # data-parallel path as well: PoseNet's backward does not depend on the cut features, so all of it runs in phase A on the auxiliary
+        # stream and _backward joins that stream before phase A's slab reduction -- its gradients are final when the late all-reduce starts
+        self.pose_stream = bool(pose_stream) and adam_fn is None
         self._graph_b = None
         self._graph = None
         self._graphs = {}

@@ -33,6 +33,9 @@ L.register_protos({
     "sde_conv_fwd_ws_bytes": ([POINTER(ConvDesc), _I], ctypes.c_size_t),
     "sde_conv_fwd_ws": ([POINTER(ConvDesc), _P, _P, _I, _P, _I, _I, _P, _P, ctypes.c_size_t, _P], c_int),
     "sde_conv_fwd_variant": ([POINTER(ConvDesc), _I], c_int),
+    "sde_conv_dgrad_bnbwd_rows": ([POINTER(ConvDesc), _I, _I], c_int),
+    "sde_conv_dgrad_bnbwd": ([POINTER(ConvDesc), _P, _P, _I, _I, _P, _P, _P, _P], c_int),
+    "sde_bn_bwd_from_part": ([_P, _I, _P, _P, _P, _LG, _I, _I, _P, _P, _P, _I, _P, _P], c_int),
     "sde_conv_set_halo_min_blocks": ([_I], c_int),
     "sde_conv_set_option": ([_I, _I], c_int),
     "sde_conv_wgrad_splits": ([POINTER(ConvDesc), _I], c_int),
@@ -70,7 +73,7 @@ L.register_protos({
 })
 
 
-OPT_PGEMM, OPT_PGEMM_DEPTH, OPT_PGEMM_3X3, OPT_PGEMM_TILE, OPT_SPLITK, OPT_WGRAD_BLOCKS, OPT_WGRAD_HALO, OPT_CONV_SMALL, OPT_WGRAD_DMA = 1, 2, 3, 4, 5, 6, 7, 8, 9      # SDE_OPT_* of include/sde_hip.h
+OPT_PGEMM, OPT_PGEMM_DEPTH, OPT_PGEMM_3X3, OPT_PGEMM_TILE, OPT_SPLITK, OPT_WGRAD_BLOCKS, OPT_WGRAD_HALO, OPT_CONV_SMALL, OPT_WGRAD_DMA, OPT_BNBWD_FUSE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10      # SDE_OPT_* of include/sde_hip.h
 
 
 def set_option(key, value):
@@ -205,6 +208,9 @@ class _Conv2d(torch.autograd.Function):
                 owner._pack_shapes = (dt, C0 + C1, ldy)            # lets WeightPacker build its job table after a first step
         b32 = _f32(bias) if bias is not None else None
         flops = 2.0 * B * OH * OW * Cout * KH * KW * Cin          # algorithmic (real channels)
+        # x0 = relu(BatchNorm(y_bn)) with this convolution as its only consumer: the data gradient below can carry BatchNorm's backward reduction
+        ent = _BN_OUT.pop(x0.data_ptr(), None) if _BN_OUT else None
+        ctx.bn_in = (ent[1], ent[2]) if (ent is not None and ent[0]() is x0 and x1 is None and not upcat and not reflect and stride == 1) else None
         y, stats = conv_raw(d, dt, wp, b32, act, Cout, ldy, want_stats, x0.device, "igemm_fwd", flops)
         ctx.save_for_backward(x0, x1, weight, y if act != ACT_NONE else None)
         ctx.params = (weight, bias)
@@ -399,6 +405,22 @@ class _Conv2d(torch.autograd.Function):
                         raise L.SdeHipError("upsample+concat source is only supported with reflection padding (decoder)")
                     if stride == 1:
                         dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1 - pad, False, OH, OW, IH, IW)
+                        rows = lib.sde_conv_dgrad_bnbwd_rows(ctypes.byref(dd), Cv, Cv) if (ctx.bn_in is not None and BNBWD_FUSED) else 0
+                        if rows > 0:
+                            # the GEMM's epilogue masks the gradient with relu'(bn(y_bn)) and leaves BatchNorm's (sum gm, sum gm * xhat) partials:
+                            # _BatchNormAct.backward finds them under the gradient's address and skips its reduce pass
+                            y_bn, bnp = ctx.bn_in
+                            part = torch.empty(rows + REDUCE_ROWS, Cv, 2, device=dev, dtype=torch.float32)
+                            dx0 = torch.empty(B, IH, IW, Cv, device=dev, dtype=dt)
+                            variant = lib.sde_conv_fwd_variant(ctypes.byref(dd), Cv) if L.PROFILE is not None else 0
+                            meta = dict(M=B * IH * IW, N=Cv, K=KH * KW * ldy, k=KH, s=1, mode=0, bytes=2 * (dz.numel() + 2 * dx0.numel())) if L.PROFILE is not None else None
+                            _timed("igemm_dgrad", flops, variant, lambda: L.check(lib.sde_conv_dgrad_bnbwd(ctypes.byref(dd), L.ptr(wd), L.ptr(dx0), Cv, Cv, L.ptr(y_bn),
+                                                                                                       L.ptr(bnp), L.ptr(part), L.stream()), "sde_conv_dgrad_bnbwd"), meta)
+                            if len(_BN_PART) > 16:
+                                _BN_PART.clear()
+                            _BN_PART[dx0.data_ptr()] = (y_bn.data_ptr(), part, rows)
+                            st["dx0"], st["dx1"] = dx0, None
+                            return
                     elif stride == 2:
                         # virtual zero-inserted gradient image: Z[2i, 2j] = dz[i, j]
                         dd = _desc(dz, None, SRC_ZEROINS, KH, KW, 1, KH - 1 - pad, False, 2 * OH - 1, 2 * OW - 1, IH, IW)
@@ -510,6 +532,10 @@ class WGradReducer:
 
 
 FUSE_BN_FINALIZE = True  # BatchNorm finalize + apply in one launch where the partial slab is short (A/B: set False)
+BNBWD_FUSED = True      # BatchNorm's backward reduce pass in the epilogue of the data-gradient GEMM that produces its incoming gradient (A/B, tests: False)
+BNBWD_HITS = 0          # times the fused path ran (tests)
+_BN_OUT = {}            # data_ptr of a residual-free BatchNorm+ReLU output -> (weakref to it, y, bnp): set by _BatchNormAct.forward, taken by _Conv2d.forward
+_BN_PART = {}           # data_ptr of the masked gradient a fused data-gradient GEMM returned -> (y.data_ptr(), partial slab, rows)
 WGRAD_DEFER = None      # HipTrainer installs a WGradReducer around backward
 MAIN_STREAM = None      # ... and the stream the backward phase runs on: the side-stream fork / lagging-join bookkeeping assumes ONE main stream
 FOLD_ROWS = 16          # SDE_WGRAD_FOLD_ROWS
@@ -617,6 +643,12 @@ class _BatchNormAct(torch.autograd.Function):
         ctx.save_for_backward(y, out if (relu and residual is not None) else None, bnp, gamma)
         ctx.params = (gamma, beta)
         ctx.cfg = (relu, residual is not None, training)
+        if training and relu and residual is None and n_out == 1 and dt != torch.float32 and C % 64 == 0 and ctx.needs_input_grad[0] and BNBWD_FUSED:
+            # candidates for the fused backward reduction: the convolution that consumes `out` (and nothing else does: n_out == 1) picks this up
+            if len(_BN_OUT) > 64:
+                _BN_OUT.clear()
+            _BN_PART.clear()                          # (entries live from a convolution's backward to this BatchNorm's backward only)
+            _BN_OUT[out.data_ptr()] = (weakref.ref(out), y, bnp)
         if n_out == 1:
             return out
         return (out,) + tuple(out.view(out.shape) for _ in range(n_out - 1))
@@ -640,13 +672,23 @@ class _BatchNormAct(torch.autograd.Function):
         M = y.numel() // C
         lib = L.lib()
         dev = y.device
-        part = torch.empty(lib.sde_reduce_num_blocks(M, C) + REDUCE_ROWS, C, 2, device=dev)
         coef = torch.empty(2, C, device=dev)
         gs, bs = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
         direct = gs is not None and bs is not None
         dgamma = gs if direct else torch.empty(C, device=dev)
         dbeta = bs if direct else torch.empty(C, device=dev)
         dy = torch.empty_like(y)
+        ent = _BN_PART.pop(grads[0].data_ptr(), None) if (_BN_PART and len(grads) == 1 and relu and not has_res) else None
+        if ent is not None and ent[0] == y.data_ptr() and grads[0].shape == y.shape and grads[0].dtype == dt:
+            # the data-gradient GEMM that produced this gradient already masked it and reduced it (sde_conv_dgrad_bnbwd): finalize + apply only
+            global BNBWD_HITS
+            BNBWD_HITS += 1
+            L.check(lib.sde_bn_bwd_from_part(L.ptr(ent[1]), ent[2], L.ptr(grads[0]), L.ptr(y), L.ptr(bnp), M, C, dtype_code(dt), L.ptr(coef), L.ptr(dgamma),
+                                             L.ptr(dbeta), int(direct), L.ptr(dy), L.stream()), "sde_bn_bwd_from_part")
+            if direct:
+                dgamma = dbeta = None
+            return dy, None, dgamma, dbeta, None, None, None, None, None, None, None, None
+        part = torch.empty(lib.sde_reduce_num_blocks(M, C) + REDUCE_ROWS, C, 2, device=dev)
         # gm = relu'(out) * (sum of the incoming gradients): needed when there is anything to mask or to sum; it is also the residual's gradient
         gm = torch.empty_like(y) if (relu or len(grads) > 1) else None
         d0, d1, d2 = (grads + [None, None])[:3]

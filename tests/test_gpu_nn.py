@@ -498,6 +498,65 @@ def test_adam_step_with_loss_scaling_keeps_torch_step_count_across_a_skipped_ste
     assert (m[:n1].cpu() - st["exp_avg"]).abs().max().item() < 1e-6 and (v[:n1].cpu() - st["exp_avg_sq"]).abs().max().item() < 1e-6
 
 
+BNBWD_CASES = [
+    # name, B, H, W, C (BatchNorm'd channels = input of the second convolution), Cout2, k2, expected kernel
+    ("1x1_per_tile", 2, 24, 40, 64, 256, 1),            # persistent GEMM, one statistics row per tile
+    ("1x1_ragged_M", 1, 7, 9, 128, 128, 1),             # M = 63 < one tile
+    ("1x1_per_workgroup", 12, 48, 160, 64, 64, 1),      # 1440 tiles on 768 persistent workgroups: partials kept in registers over a workgroup's tiles
+    ("1x1_wide", 3, 12, 20, 512, 128, 1),               # eight N tiles
+    ("3x3_halo", 4, 48, 160, 64, 64, 3),                # LDS-halo 3x3 kernel (240 workgroups)
+    ("3x3_halo_ragged", 12, 20, 36, 128, 128, 3),       # 8x16 tiles overhang the image
+    ("3x3_small", 1, 8, 16, 64, 64, 3),                 # too few tiles for the halo kernel: persistent GEMM with filter taps
+]
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", BNBWD_CASES, ids=[c[0] for c in BNBWD_CASES])
+def test_bn_backward_reduce_in_the_dgrad_epilogue(NN, case, dt):
+    """conv_a -> BatchNorm + ReLU (no residual, one consumer) -> conv_b, backward: the data gradient of conv_b masks its output with relu'(bn(y)) and
+    leaves BatchNorm's (sum gm, sum gm * xhat) partials in its epilogue (sde_conv_dgrad_bnbwd + sde_bn_bwd_from_part) against the separate
+    bn_bwd_reduce pass over the same tensors (same summands, another order), and -- on the small cases -- against torch-CPU fp32 autograd on the
+    16-bit-rounded operands."""
+    name, B, H, W, C, Cout2, k2 = case
+    if dt == torch.float16 and name not in ("1x1_per_tile", "3x3_halo"):
+        pytest.skip("fp16 instantiation: one case per kernel")
+    g = torch.Generator().manual_seed(B * 1000 + C + k2)
+    Cin = 64
+    x = (torch.randn(B, Cin, H, W, generator=g) + 0.2).to(dt).float()
+    wa = (torch.randn(C, Cin, 1, 1, generator=g) / math.sqrt(Cin)).to(dt).float()
+    wb = (torch.randn(Cout2, C, k2, k2, generator=g) / math.sqrt(C * k2 * k2)).to(dt).float()
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.3
+    go = torch.randn(B, Cout2, H, W, generator=g).to(dt).float()
+    res = []
+    for fused in (False, True):
+        NN.BNBWD_FUSED = fused
+        try:
+            xd = nhwc(x, dt, 8).requires_grad_(True)
+            wad, wbd, gd, bd = (t.clone().to(dev).requires_grad_(True) for t in (wa, wb, gamma, beta))
+            hits = NN.BNBWD_HITS
+            y, stats = NN.conv2d(xd, wad, None, stride=1, pad=0, bn_stats=True)
+            a = NN.batch_norm_act(y, stats, gd, bd, torch.zeros(C, device=dev), torch.ones(C, device=dev), relu=True)
+            out = NN.conv2d(a, wbd, None, stride=1, pad=k2 // 2)
+            out.backward(nhwc(go, dt, 8))
+            torch.cuda.synchronize()
+            assert NN.BNBWD_HITS - hits == (1 if fused else 0), f"{name}: fused path {'not ' if fused else ''}taken"
+            res.append([t.detach().float().cpu() for t in (out, xd.grad, wad.grad, wbd.grad, gd.grad, bd.grad)])
+        finally:
+            NN.BNBWD_FUSED = True
+    for nm, u, f in zip(("out", "dX", "dWa", "dWb", "dgamma", "dbeta"), res[0], res[1]):
+        assert relerr(f, u) < (1e-6 if nm in ("out", "dWb") else 3e-3), f"{name} {nm}: fused vs separate {relerr(f, u):.3e}"
+    if B * H * W <= 4000:
+        xr, war, wbr, gr, br = (t.clone().requires_grad_(True) for t in (x, wa, wb, gamma, beta))
+        yc = F.conv2d(xr, war)
+        yc = yc + (yc.detach().to(dt).float() - yc.detach())          # the GPU path stores the convolution output in 16 bits before normalising
+        ar = F.relu(F.batch_norm(yc, torch.zeros(C), torch.ones(C), gr, br, True, 0.1, 1e-5))
+        F.conv2d(ar, wbr, None, 1, k2 // 2).backward(go)
+        check(nchw(res[1][1].to(dev), Cin), xr.grad, torch.bfloat16, "dX vs cpu", bf16_tol=3e-2)
+        check(res[1][2], war.grad, torch.bfloat16, "dWa vs cpu", bf16_tol=3e-2)
+        check(res[1][4], gr.grad, torch.bfloat16, "dgamma vs cpu", bf16_tol=3e-2)
+        check(res[1][5], br.grad, torch.bfloat16, "dbeta vs cpu", bf16_tol=3e-2)
+
+
 def test_full_size_conv_properties(NN):
     """BASELINE size (B=12, 48x160, 64->64 3x3, bf16): linearity in the input and agreement of a strided sub-sample with fp32 CPU."""
     g = torch.Generator().manual_seed(5)
