@@ -314,6 +314,13 @@ int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B,
                     void* out, sde_stream_t stream);
 int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,
                     float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream);
+/* The same with a residual input: the normalised tensor is x + res (summed in fp32, never materialised) -- layers01.py:L74-76 ResidualConv:
+ * normalize(x_out + shortcut).  res may be NULL (= the calls above); with res, C / (16-byte group) must divide 256.  Backward: dx is the
+ * gradient of BOTH x and res. */
+int sde_gn_relu_res_fwd(const void* x, const void* res, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype,
+                        float* part, float* gnp, void* out, sde_stream_t stream);
+int sde_gn_relu_res_bwd(const void* dout, const void* out, const void* x, const void* res, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu,
+                        int dtype, float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * PackNet's 3-D convolution (layers01.py:L223-298): x.unsqueeze(1) -> nn.Conv3d(1, 8, 3, padding=1) -> view(b, 8*D, h, w) on NHWC data:
@@ -324,6 +331,25 @@ int sde_conv3d_dgrad(const void* dy, const float* w, int B, int H, int W, int D,
 int sde_conv3d_wgrad_num_blocks(int B, int H, int W, int D, int dtype);
 int sde_conv3d_wgrad(const void* x, const void* dy, int B, int H, int W, int D, int dtype, float* part, float* dw, float* dbias, int accumulate,
                      sde_stream_t stream);
+
+/* PackNet01's data movement (csrc/packnet.hip), NHWC, 16 bytes per lane, each other's backward:
+ *   sde_space_to_depth: layers01.py:L138-160 `packing` (r = 2): x [B,H,W,C] -> y [B,H/2,W/2,4C], y[b,i,j,c*4+di*2+dj] = x[b,2i+di,2j+dj,c]
+ *   sde_depth_to_space: nn.PixelShuffle(2) of layers01.py:L262-298:       x [B,H,W,C4] -> y [B,2H,2W,C4/4], the inverse permutation
+ * sde_concat_fwd: PackNet01.py:L150-199 torch.cat([unpacked, skip(, nearest_x2(inv_depth))], 1) (version A) or [unpacked + skip(, ...)] (add = 1,
+ * version B: C1 == C0) as ONE pass: out [B,H,W,Ct], Ct = channels used rounded up to the 16-byte group, fill = exact zeros; inv [B,H/2,W/2] fp32
+ * or NULL.  sde_concat_bwd: d0 [B,H,W,C0] (add mode: also the gradient of p1), d1 [B,H,W,C1] (concat mode), d_inv [B,H/2,W/2] fp32 (2x2 sums) or NULL. */
+int sde_space_to_depth(const void* x, int B, int H, int W, int C, int dtype, void* y, sde_stream_t stream);
+int sde_depth_to_space(const void* x, int B, int H, int W, int C4, int dtype, void* y, sde_stream_t stream);
+int sde_concat_fwd(const void* p0, const void* p1, const float* inv, int add, int B, int H, int W, int C0, int C1, int Ct, int dtype, void* out,
+                   sde_stream_t stream);
+int sde_concat_bwd(const void* dout, int add, int B, int H, int W, int C0, int C1, int Ct, int dtype, void* d0, void* d1, float* d_inv, sde_stream_t stream);
+/* layers01.py:L105-133 InvDepth's tail + PackNet01.py:L120-123,L199 scale_inv_depth: logit = y[...,0] ([B,H,W,ld], the one-channel convolution's padded
+ * output) -> inv [B,H,W] fp32 = sigmoid(logit) / min_depth_head (fed to the next decoder level) and depth [B,1,H,W] fp32 =
+ * 1 / (1/max_depth + (1/min_depth - 1/max_depth) * inv), mirrored along x when flip.  Backward: d_inv and / or d_depth (either may be NULL) -> dy. */
+int sde_inv_depth_head_fwd(const void* y, int B, int H, int W, int ld, float min_depth_head, float min_depth, float max_depth, int flip, int dtype, float* inv,
+                           float* depth, sde_stream_t stream);
+int sde_inv_depth_head_bwd(const void* y, const float* d_inv, const float* d_depth, int B, int H, int W, int ld, float min_depth_head, float min_depth,
+                           float max_depth, int flip, int dtype, void* dy, sde_stream_t stream);
 
 /* torch.optim.Adam / AdamW step (projects/MonoDepth2/train.py:L50-57, projects/Supervised/train.py:L77-81) over ONE flat fp32 buffer.
  * The descriptor is HOST memory and is copied into the kernel arguments (nothing to upload or keep alive): segment s covers

@@ -908,7 +908,8 @@ __device__ __forceinline__ void fixed_order_group_sum(const float* a1, const flo
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ part /*[B][GN_CHUNKS][C][2]*/) {
+__global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, const T* __restrict__ res, int HW, int C, float* __restrict__ part /*[B][GN_CHUNKS][C][2]*/) {
+    // res (optional, vector path only -- host-checked): the normalised tensor is x + res (layers01.py:L74-76 ResidualConv: x_out + shortcut), summed in fp32
     extern __shared__ float sh[];   // [2][C]
     const int b = blockIdx.y, ch = blockIdx.x;
     for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
@@ -925,9 +926,16 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < V; ++e) { v1[e] = 0.f; v2[e] = 0.f; }
         const long groups = (long)(p1 - p0) * cch;
+        const T* rbase = res ? res + ((long)b * HW + p0) * C : nullptr;
         for (long i = threadIdx.x; i < groups; i += 256) {
             float v[V];
             load_vec<T>(base + i * V, v);
+            if (rbase) {
+                float r[V];
+                load_vec<T>(rbase + i * V, r);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] += r[e];
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) { v1[e] += v[e]; v2[e] += v[e] * v[e]; }
         }
@@ -995,7 +1003,7 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float* __restrict
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ gnp, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ gnp, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int B, int HW, int C, int G, int relu, T* __restrict__ out) {
     constexpr int V = VecOf<T>::V;                 // 16 bytes per lane
     const int cch = C / V, cpg = C / G;
@@ -1004,6 +1012,12 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
         const int c0 = (int)(i % cch) * V, b = (int)(i / ((long)HW * cch));
         float v[V];
         load_vec<T>(x + i * V, v);
+        if (res) {
+            float r[V];
+            load_vec<T>(res + i * V, r);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] += r[e];
+        }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const float* st = gnp + ((size_t)b * G + (c0 + e) / cpg) * 2;
@@ -1015,7 +1029,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x, 
 
 // backward stage 1: per (sample, chunk) per-channel partial sums of dz and dz*xhat (dz = dout * relu mask)
 template <typename T>
-__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ res,
                                                            const float* __restrict__ gnp, int HW, int C, int G, int relu,
                                                            float* __restrict__ part /*[B][GN_CHUNKS][C][2]*/) {
     extern __shared__ float sh[];
@@ -1041,6 +1055,12 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const T* __restrict__
             load_vec<T>(dout + base + i * V, d);
             if (relu) load_vec<T>(out + base + i * V, o);
             load_vec<T>(x + base + i * V, xv);
+            if (res) {
+                float rr[V];
+                load_vec<T>(res + base + i * V, rr);
+#pragma unroll
+                for (int e = 0; e < V; ++e) xv[e] += rr[e];
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 float de = d[e];
@@ -1130,7 +1150,7 @@ __global__ void __launch_bounds__(64) gn_bwd_finalize_kernel(const float* __rest
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x,
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out, const T* __restrict__ x, const T* __restrict__ res,
                                                            const float* __restrict__ gnp, const float* __restrict__ coef, const float* __restrict__ gamma,
                                                            int B, int HW, int C, int G, int relu, T* __restrict__ dx) {
     constexpr int V = VecOf<T>::V;
@@ -1142,6 +1162,12 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const T* __restrict__
         load_vec<T>(dout + i * V, d);
         if (relu) load_vec<T>(out + i * V, o);
         load_vec<T>(x + i * V, xv);
+        if (res) {
+            float rr[V];
+            load_vec<T>(res + i * V, rr);
+#pragma unroll
+            for (int e = 0; e < V; ++e) xv[e] += rr[e];
+        }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const size_t gi = ((size_t)b * G + (c0 + e) / cpg) * 2;
@@ -1544,42 +1570,56 @@ int sde_depth_head_bwd_bias(const void* y, const float* ddepth, int B, int H, in
 
 int sde_gn_relu_fwd(const void* x, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype, float* part, float* gnp,
                     void* out, sde_stream_t stream) {
+    return sde_gn_relu_res_fwd(x, nullptr, gamma, beta, B, HW, C, G, eps, relu, dtype, part, gnp, out, stream);
+}
+
+static bool gn_vector_path(int C, int dtype) { const int V = SDE_IS16(dtype) ? 8 : 4; return C % V == 0 && 256 % (C / V) == 0; }
+
+int sde_gn_relu_res_fwd(const void* x, const void* res, const float* gamma, const float* beta, int B, int HW, int C, int G, float eps, int relu, int dtype,
+                        float* part, float* gnp, void* out, sde_stream_t stream) {
     SDE_CHECK_ARG(x && gamma && beta && part && gnp && out && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "sde_gn_relu_fwd: bad argument");
     SDE_CHECK_ARG(C % (SDE_IS16(dtype) ? 8 : 4) == 0, "sde_gn_relu_fwd: C=%d must be a multiple of the 16-byte group", C);
+    SDE_CHECK_ARG(!res || gn_vector_path(C, dtype), "sde_gn_relu_res_fwd: the residual form needs C / (16-byte group) to divide 256 (C=%d)", C);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = 2 * (size_t)C * sizeof(float);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)x, HW, C, part),
-               hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)x, HW, C, part),
-               hipLaunchKernelGGL(gn_stats_kernel<half_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const half_t*)x, HW, C, part));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)x, (const float*)res, HW, C, part),
+               hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)res, HW, C, part),
+               hipLaunchKernelGGL(gn_stats_kernel<half_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const half_t*)x, (const half_t*)res, HW, C, part));
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/stats");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, s, part, B, C, G, HW, eps, gnp);
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/finalize");
     const int nb = grid_for((long)B * HW * (C / (SDE_IS16(dtype) ? 8 : 4)));
-    DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, gnp, gamma, beta, B, HW, C, G, relu, (float*)out),
-               hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, gnp, gamma, beta, B, HW, C, G, relu, (bf16_t*)out),
-               hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)x, gnp, gamma, beta, B, HW, C, G, relu, (half_t*)out));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)res, gnp, gamma, beta, B, HW, C, G, relu, (float*)out),
+               hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)res, gnp, gamma, beta, B, HW, C, G, relu, (bf16_t*)out),
+               hipLaunchKernelGGL(gn_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)x, (const half_t*)res, gnp, gamma, beta, B, HW, C, G, relu, (half_t*)out));
     SDE_CHECK_LAUNCH("sde_gn_relu_fwd/apply");
     return SDE_OK;
 }
 
 int sde_gn_relu_bwd(const void* dout, const void* out, const void* x, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu, int dtype,
                     float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream) {
+    return sde_gn_relu_res_bwd(dout, out, x, nullptr, gnp, gamma, B, HW, C, G, relu, dtype, part, coef, dgamma, dbeta, accumulate_params, dx, stream);
+}
+
+int sde_gn_relu_res_bwd(const void* dout, const void* out, const void* x, const void* res, const float* gnp, const float* gamma, int B, int HW, int C, int G, int relu,
+                        int dtype, float* part, float* coef, float* dgamma, float* dbeta, int accumulate_params, void* dx, sde_stream_t stream) {
     SDE_CHECK_ARG(dout && out && x && gnp && gamma && part && coef && dgamma && dbeta && dx && C % G == 0, "sde_gn_relu_bwd: bad argument");
+    SDE_CHECK_ARG(!res || gn_vector_path(C, dtype), "sde_gn_relu_res_bwd: the residual form needs C / (16-byte group) to divide 256 (C=%d)", C);
     SDE_CHECK_ARG(C % (SDE_IS16(dtype) ? 8 : 4) == 0, "sde_gn_relu_bwd: C=%d must be a multiple of the 16-byte group", C);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)x, gnp, HW, C, G, relu, part),
-               hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, HW, C, G, relu, part),
-               hipLaunchKernelGGL(gn_bwd_stats_kernel<half_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const half_t*)dout, (const half_t*)out, (const half_t*)x, gnp, HW, C, G, relu, part));
+               hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const float*)dout, (const float*)out, (const float*)x, (const float*)res, gnp, HW, C, G, relu, part),
+               hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, (const bf16_t*)res, gnp, HW, C, G, relu, part),
+               hipLaunchKernelGGL(gn_bwd_stats_kernel<half_t>, dim3(GN_CHUNKS, B), dim3(256), lds, s, (const half_t*)dout, (const half_t*)out, (const half_t*)x, (const half_t*)res, gnp, HW, C, G, relu, part));
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/stats");
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * G + C), dim3(64), 0, s, part, gamma, B, C, G, HW, coef, dgamma, dbeta, accumulate_params);
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/finalize");
     const int nb = grid_for((long)B * HW * (C / (SDE_IS16(dtype) ? 8 : 4)));
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, gnp, coef, gamma, B, HW, C, G, relu, (float*)dx),
-               hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, gnp, coef, gamma, B, HW, C, G, relu, (bf16_t*)dx),
-               hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dout, (const half_t*)out, (const half_t*)x, gnp, coef, gamma, B, HW, C, G, relu, (half_t*)dx));
+               hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)dout, (const float*)out, (const float*)x, (const float*)res, gnp, coef, gamma, B, HW, C, G, relu, (float*)dx),
+               hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, (const bf16_t*)res, gnp, coef, gamma, B, HW, C, G, relu, (bf16_t*)dx),
+               hipLaunchKernelGGL(gn_bwd_apply_kernel<half_t>, dim3(nb), dim3(256), 0, s, (const half_t*)dout, (const half_t*)out, (const half_t*)x, (const half_t*)res, gnp, coef, gamma, B, HW, C, G, relu, (half_t*)dx));
     SDE_CHECK_LAUNCH("sde_gn_relu_bwd/apply");
     return SDE_OK;
 }

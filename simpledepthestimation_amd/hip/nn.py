@@ -63,6 +63,14 @@ L.register_protos({
     "sde_depth_head_bwd": ([_P, _P, _I, _I, _I, _I, _F, _F, _I, _I, _P, _P], c_int),
     "sde_gn_relu_fwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P], c_int),
     "sde_gn_relu_bwd": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P], c_int),
+    "sde_gn_relu_res_fwd": ([_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P], c_int),
+    "sde_gn_relu_res_bwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P], c_int),
+    "sde_space_to_depth": ([_P, _I, _I, _I, _I, _I, _P, _P], c_int),
+    "sde_depth_to_space": ([_P, _I, _I, _I, _I, _I, _P, _P], c_int),
+    "sde_concat_fwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P], c_int),
+    "sde_concat_bwd": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P], c_int),
+    "sde_inv_depth_head_fwd": ([_P, _I, _I, _I, _I, _F, _F, _F, _I, _I, _P, _P, _P], c_int),
+    "sde_inv_depth_head_bwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _I, _I, _P, _P], c_int),
     "sde_conv3d_fwd": ([_P, _P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_conv3d_dgrad": ([_P, _P, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_conv3d_wgrad_num_blocks": ([_I, _I, _I, _I, _I], c_int),
@@ -813,22 +821,27 @@ def depth_head(y, min_depth, max_depth, flip=False):
 # ---------------------------------------------------------------------------------------------------------------
 class _GroupNormReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, relu):
+    def forward(ctx, x, gamma, beta, groups, eps, relu, res=None):
         B, H, W, C = x.shape
         dev = x.device
         part = torch.empty(B, GN_CHUNKS, C, 2, device=dev)
         gnp = torch.empty(B, groups, 2, device=dev)
         out = torch.empty_like(x)
-        L.check(L.lib().sde_gn_relu_fwd(L.ptr(x.contiguous()), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), B, H * W, C, groups, eps, int(relu), dtype_code(x.dtype),
-                                        L.ptr(part), L.ptr(gnp), L.ptr(out), L.stream()), "sde_gn_relu_fwd")
-        ctx.save_for_backward(x, out, gnp, gamma)
+        x = x.contiguous()
+        if res is not None:
+            if res.shape != x.shape or res.dtype != x.dtype:
+                raise L.SdeHipError("group_norm_relu: the residual must have the input's shape and dtype")
+            res = res.contiguous()
+        L.check(L.lib().sde_gn_relu_res_fwd(L.ptr(x), L.ptr(res), L.ptr(_f32(gamma)), L.ptr(_f32(beta)), B, H * W, C, groups, eps, int(relu), dtype_code(x.dtype),
+                                            L.ptr(part), L.ptr(gnp), L.ptr(out), L.stream()), "sde_gn_relu_res_fwd")
+        ctx.save_for_backward(x, out, gnp, gamma, res)
         ctx.params = (gamma, beta)
         ctx.cfg = (groups, relu)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, out, gnp, gamma = ctx.saved_tensors
+        x, out, gnp, gamma, res = ctx.saved_tensors
         groups, relu = ctx.cfg
         B, H, W, C = x.shape
         dev = x.device
@@ -839,23 +852,134 @@ class _GroupNormReLU(torch.autograd.Function):
         dgamma = gs if direct else torch.empty(C, device=dev)
         dbeta = bs if direct else torch.empty(C, device=dev)
         dx = torch.empty_like(x)
-        L.check(L.lib().sde_gn_relu_bwd(L.ptr(dout.contiguous()), L.ptr(out), L.ptr(x), L.ptr(gnp), L.ptr(_f32(gamma)), B, H * W, C, groups, int(relu),
-                                        dtype_code(x.dtype), L.ptr(part), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), int(direct), L.ptr(dx), L.stream()),
-                "sde_gn_relu_bwd")
+        L.check(L.lib().sde_gn_relu_res_bwd(L.ptr(dout.contiguous()), L.ptr(out), L.ptr(x), L.ptr(res), L.ptr(gnp), L.ptr(_f32(gamma)), B, H * W, C, groups, int(relu),
+                                            dtype_code(x.dtype), L.ptr(part), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), int(direct), L.ptr(dx), L.stream()),
+                "sde_gn_relu_res_bwd")
         if direct:
             dgamma = dbeta = None
-        return dx, dgamma, dbeta, None, None, None
+        # the normalised tensor is x + res: both receive the same gradient (one tensor, no copy)
+        return dx, dgamma, dbeta, None, None, None, (dx if res is not None else None)
 
 
 GN_CHUNKS = 64          # SDE_GN_CHUNKS
 GN_ACT = {False: 0, True: 1, "none": 0, "relu": 1, "elu": 2}
 
 
-def group_norm_relu(x, gamma, beta, groups=16, eps=1e-5, relu=True):
-    """GroupNorm + activation; relu: True / "relu" (PoseNet.py:L13-20), "elu" (layers01.py:L33-40), False / "none"."""
+def group_norm_relu(x, gamma, beta, groups=16, eps=1e-5, relu=True, residual=None):
+    """GroupNorm + activation; relu: True / "relu" (PoseNet.py:L13-20), "elu" (layers01.py:L33-40), False / "none".
+    residual: the normalised tensor is x + residual (layers01.py:L74-76), summed inside the kernels."""
     if x.shape[-1] != gamma.numel():
         raise L.SdeHipError("group_norm_relu: channel padding is not supported (PoseNet / PackNet channels are multiples of 16)")
-    return _GroupNormReLU.apply(x, gamma, beta, int(groups), float(eps), GN_ACT[relu])
+    return _GroupNormReLU.apply(x, gamma, beta, int(groups), float(eps), GN_ACT[relu], residual)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PackNet01's data movement (csrc/packnet.hip): space-to-depth / depth-to-space, channel concatenation, the inverse-depth head
+# ---------------------------------------------------------------------------------------------------------------
+def _s2d(x, inverse):
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    if inverse:
+        y = torch.empty(B, 2 * H, 2 * W, C // 4, device=x.device, dtype=x.dtype)
+        L.check(L.lib().sde_depth_to_space(L.ptr(x), B, H, W, C, dtype_code(x.dtype), L.ptr(y), L.stream()), "sde_depth_to_space")
+    else:
+        y = torch.empty(B, H // 2, W // 2, 4 * C, device=x.device, dtype=x.dtype)
+        L.check(L.lib().sde_space_to_depth(L.ptr(x), B, H, W, C, dtype_code(x.dtype), L.ptr(y), L.stream()), "sde_space_to_depth")
+    return y
+
+
+class _SpaceToDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, inverse):
+        ctx.inverse = inverse
+        return _s2d(x, inverse)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _s2d(dy, not ctx.inverse), None
+
+
+def space_to_depth(x):
+    """layers01.py:L138-160 `packing` (r = 2) on NHWC: out[b,y,x,c*4+dy*2+dx] = in[b,2y+dy,2x+dx,c]."""
+    return _SpaceToDepth.apply(x, False)
+
+
+def depth_to_space(x):
+    """nn.PixelShuffle(2) on NHWC: out[b,2y+dy,2x+dx,c] = in[b,y,x,c*4+dy*2+dx]."""
+    return _SpaceToDepth.apply(x, True)
+
+
+class _Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p0, p1, inv, add):
+        p0 = p0.contiguous()
+        B, H, W, C0 = p0.shape
+        V = vec_of(p0.dtype)
+        C1 = p1.shape[3] if p1 is not None else 0
+        if p1 is not None:
+            p1 = p1.contiguous()
+            if p1.dtype != p0.dtype or p1.shape[:3] != p0.shape[:3]:
+                raise L.SdeHipError("concat: sources differ in dtype or spatial size")
+        if inv is not None:
+            inv = inv.contiguous()
+            if inv.dtype != torch.float32 or tuple(inv.shape) != (B, H // 2, W // 2):
+                raise L.SdeHipError(f"concat: the inverse-depth map must be fp32 [B, H/2, W/2], got {tuple(inv.shape)} {inv.dtype}")
+        Ct = pad_to(C0 + (0 if add else C1) + (1 if inv is not None else 0), V)
+        out = torch.empty(B, H, W, Ct, device=p0.device, dtype=p0.dtype)
+        L.check(L.lib().sde_concat_fwd(L.ptr(p0), L.ptr(p1), L.ptr(inv), int(add), B, H, W, C0, C1, Ct, dtype_code(p0.dtype), L.ptr(out), L.stream()), "sde_concat_fwd")
+        ctx.cfg = (B, H, W, C0, C1, Ct, add, inv is not None, p1 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, H, W, C0, C1, Ct, add, has_inv, has_p1 = ctx.cfg
+        dout = dout.contiguous()
+        d0 = torch.empty(B, H, W, C0, device=dout.device, dtype=dout.dtype)
+        d1 = torch.empty(B, H, W, C1, device=dout.device, dtype=dout.dtype) if (has_p1 and not add) else None
+        dinv = torch.empty(B, H // 2, W // 2, device=dout.device, dtype=torch.float32) if (has_inv and ctx.needs_input_grad[2]) else None
+        L.check(L.lib().sde_concat_bwd(L.ptr(dout), int(add), B, H, W, C0, C1, Ct, dtype_code(dout.dtype), L.ptr(d0), L.ptr(d1), L.ptr(dinv), L.stream()), "sde_concat_bwd")
+        return d0, (d0 if (add and has_p1) else d1), dinv, None
+
+
+def concat(p0, p1=None, inv_depth=None, add=False):
+    """cat([p0, p1(, nearest_x2(inv_depth))], channel) -- or [p0 + p1(, ...)] with add=True -- zero-filled to the 16-byte group, in one pass
+    (PackNet01.py:L150-199).  inv_depth: fp32 [B, H/2, W/2]."""
+    return _Concat.apply(p0, p1, inv_depth, bool(add))
+
+
+class _InvDepthHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, min_depth_head, min_depth, max_depth, flip):
+        y = y.contiguous()
+        B, H, W, ld = y.shape
+        inv = torch.empty(B, H, W, device=y.device, dtype=torch.float32)
+        depth = torch.empty(B, 1, H, W, device=y.device, dtype=torch.float32)
+        L.check(L.lib().sde_inv_depth_head_fwd(L.ptr(y), B, H, W, ld, min_depth_head, min_depth, max_depth, int(flip), dtype_code(y.dtype), L.ptr(inv), L.ptr(depth),
+                                               L.stream()), "sde_inv_depth_head_fwd")
+        ctx.save_for_backward(y)
+        ctx.cfg = (min_depth_head, min_depth, max_depth, flip)
+        ctx.set_materialize_grads(False)
+        return inv, depth
+
+    @staticmethod
+    def backward(ctx, d_inv, d_depth):
+        (y,) = ctx.saved_tensors
+        if d_inv is None and d_depth is None:
+            return None, None, None, None, None
+        mdh, mn, mx, flip = ctx.cfg
+        B, H, W, ld = y.shape
+        dy = torch.empty_like(y)
+        di = d_inv.contiguous().float() if d_inv is not None else None
+        dd = d_depth.contiguous().float() if d_depth is not None else None
+        L.check(L.lib().sde_inv_depth_head_bwd(L.ptr(y), L.ptr(di), L.ptr(dd), B, H, W, ld, mdh, mn, mx, int(flip), dtype_code(y.dtype), L.ptr(dy), L.stream()),
+                "sde_inv_depth_head_bwd")
+        return dy, None, None, None, None
+
+
+def inv_depth_head(y, min_depth_head, min_depth, max_depth, flip=False):
+    """(sigmoid(y[...,0]) / min_depth_head  [B,H,W] fp32,  disp_to_depth(.)[1] [B,1,H,W] fp32, mirrored along x when flip) -- layers01.py:L105-133 and
+    PackNet01.py:L120-123,L199."""
+    return _InvDepthHead.apply(y, float(min_depth_head), float(min_depth), float(max_depth), bool(flip))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -79,8 +79,8 @@ class HipGroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_channels))
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
-    def forward(self, x, relu=True):
-        return HN.group_norm_relu(x, self.weight, self.bias, self.num_groups, self.eps, relu)
+    def forward(self, x, relu=True, residual=None):
+        return HN.group_norm_relu(x, self.weight, self.bias, self.num_groups, self.eps, relu, residual)
 
 
 def conv_bn(conv, bn, x, residual=None, relu=True, n_out=1):

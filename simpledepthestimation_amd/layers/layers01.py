@@ -1,8 +1,8 @@
 """PackNet building blocks on the HIP kernels (reference: detectron2/layers/layers01.py:L11-298), NHWC activations.
 
 Module / parameter names equal the reference's (``conv_base``, ``normalize``, ``conv3d`` ...), so its checkpoints load unchanged.
-Pure data movement (space-to-depth ``packing``, ``nn.PixelShuffle``, channel concatenation) is a torch view/permute/copy on the device;
-every arithmetic op (convolutions, 3-D convolution, GroupNorm + ELU) runs in libsde_hip.so.
+Everything between the convolutions runs in libsde_hip.so as well (csrc/packnet.hip): space-to-depth ``packing`` and ``nn.PixelShuffle`` are one
+16-byte-per-lane permutation kernel each (each other's backward), the residual sum lives inside GroupNorm, the inverse-depth head is one kernel.
 """
 import torch
 import torch.nn as nn
@@ -47,7 +47,7 @@ class ResidualConv(nn.Module):
     def forward(self, x):
         x_out = self.conv2(self.conv1(x))
         shortcut = self.conv3(x)
-        return self.normalize(x_out + shortcut, relu="elu")
+        return self.normalize(x_out, relu="elu", residual=shortcut)      # normalize(x_out + shortcut): the sum is formed inside the GroupNorm kernels
 
 
 def ResidualBlock(in_channels, out_channels, num_blocks, stride, dropout=None):
@@ -69,23 +69,23 @@ class InvDepth(nn.Module):
         self.conv1 = HipConv2d(in_channels, out_channels, 3, stride=1, padding=1, bias=True)
         _xavier_(self.conv1)
 
-    def forward(self, x):
-        logit = self.conv1(x)[..., 0].float()        # channel 0 of the padded 16-byte group
-        return torch.sigmoid(logit) / self.min_depth
+    def forward(self, x, min_depth=0.1, max_depth=80.0, flip=False):
+        """Returns (inverse depth [B,H,W] fp32 = sigmoid / min_depth of this head, metric depth [B,1,H,W] fp32 = PackNet01.scale_inv_depth(.)[1])."""
+        return HN.inv_depth_head(self.conv1(x), self.min_depth, min_depth, max_depth, flip)
 
 
 def packing(x, r=2):
     """Space-to-depth on NHWC: out[b,y,x, c*r*r + dy*r + dx] = in[b, y*r+dy, x*r+dx, c] (layers01.py:L138-160)."""
-    B, H, W, C = x.shape
-    oh, ow = H // r, W // r
-    return x.reshape(B, oh, r, ow, r, C).permute(0, 1, 3, 5, 2, 4).reshape(B, oh, ow, C * r * r)
+    if r != 2:
+        raise NotImplementedError("packing with r != 2 (PackNet01 uses 2)")
+    return HN.space_to_depth(x)
 
 
 def pixel_shuffle(x, r=2):
     """nn.PixelShuffle(r) on NHWC: out[b, y*r+dy, x*r+dx, c] = in[b,y,x, c*r*r + dy*r + dx]."""
-    B, H, W, C = x.shape
-    c = C // (r * r)
-    return x.reshape(B, H, W, c, r, r).permute(0, 1, 4, 2, 5, 3).reshape(B, H * r, W * r, c)
+    if r != 2:
+        raise NotImplementedError("pixel_shuffle with r != 2 (PackNet01 uses 2)")
+    return HN.depth_to_space(x)
 
 
 class _Conv3dParams(nn.Module):

@@ -37,20 +37,6 @@ def _decoder_widths(version):
     return table
 
 
-def _cat(parts, vec):
-    """Channel concatenation of NHWC tensors, zero-padded to the next multiple of the 16-byte group."""
-    used = sum(p.shape[-1] for p in parts)
-    fill = (-used) % vec
-    if fill:
-        parts = [*parts, parts[0].new_zeros(*parts[0].shape[:3], fill)]
-    return torch.cat(parts, -1)
-
-
-def _up2(disp):
-    """Nearest x2 of a [B,H,W] map (the reference's parameter-free ``unpack_disp*`` modules)."""
-    return disp.repeat_interleave(2, 1).repeat_interleave(2, 2)
-
-
 @DEPTH_NET_REGISTRY.register()
 class PackNet01(nn.Module):
     def __init__(self, cfg, **kwargs):
@@ -81,12 +67,9 @@ class PackNet01(nn.Module):
         return disp_to_depth(disp, min_depth=MIN_DEPTH, max_depth=self.max_depth)
 
     def _join(self, unpacked, skip, disp_below=None):
-        parts = [unpacked, skip] if self.version == "A" else [unpacked + skip]
-        if disp_below is not None:
-            parts.append(_up2(disp_below).unsqueeze(-1).to(self.dtype))
-        if len(parts) == 1:
-            return parts[0]
-        return _cat(parts, 4 if self.dtype == torch.float32 else 8)
+        """The input of iconv_l (PackNet01.py:L150-199): cat([unpacked, skip(, nearest_x2(inverse depth of the level below))]) in version A,
+        [unpacked + skip(, ...)] in version B -- one kernel (sde_concat_fwd), zero-filled to the 16-byte group."""
+        return HN.concat(unpacked, skip, disp_below, add=self.version != "A")
 
     def forward(self, batch):
         flip = bool(batch.get("flip", False))
@@ -100,15 +83,14 @@ class PackNet01(nn.Module):
             feat = getattr(self, f"conv{lvl}")(packed[lvl - 1])
             packed[lvl] = getattr(self, f"pack{lvl}")(feat)
         # decoder, coarse to fine; the inverse depth of level l+1 is an extra input channel of levels 3..1
-        feat, disp = packed[5], {}
+        feat, disp, dmap = packed[5], {}, {}
         for lvl in range(5, 0, -1):
             joined = self._join(getattr(self, f"unpack{lvl}")(feat), packed[lvl - 1], disp.get(lvl + 1))
             feat = getattr(self, f"iconv{lvl}")(joined)
             if lvl in DISP_LEVELS:
-                disp[lvl] = getattr(self, f"disp{lvl}_layer")(feat)
-        depth = [self.scale_inv_depth(disp[lvl].unsqueeze(1))[1] for lvl in DISP_LEVELS]
-        if flip:
-            depth = [d.flip(3) for d in depth]
+                # (inverse depth for the level above, metric depth = scale_inv_depth(.)[1] flipped back): one kernel
+                disp[lvl], dmap[lvl] = getattr(self, f"disp{lvl}_layer")(feat, MIN_DEPTH, self.max_depth, flip)
+        depth = [dmap[lvl] for lvl in DISP_LEVELS]
         if self.upsample_depth:
             depth = [F.interpolate(d.contiguous(), size=tuple(stem.shape[1:3]), mode="nearest") for d in depth]
         batch["depth_pred"] = depth

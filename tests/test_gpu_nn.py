@@ -557,6 +557,122 @@ def test_bn_backward_reduce_in_the_dgrad_epilogue(NN, case, dt):
         check(res[1][5], br.grad, torch.bfloat16, "dbeta vs cpu", bf16_tol=3e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "fp16"])
+def test_space_to_depth_and_depth_to_space(NN, dtype):
+    """layers01.py:L138-160 `packing` and nn.PixelShuffle(2) on NHWC as one permutation kernel each (csrc/packnet.hip), each other's backward: vs the
+    reference's view / permute chain and F.pixel_shuffle on NCHW, exactly (pure data movement)."""
+    g = torch.Generator().manual_seed(40)
+    B, C, H, W = 2, 16, 6, 10
+    x = torch.randn(B, C, H, W, generator=g).to(dtype).float()
+    # the reference's packing (layers01.py:L138-160): view(b,c,oh,r,ow,r) -> permute(0,1,3,5,2,4) -> view(b, c*r*r, oh, ow)
+    ref = x.view(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 3, 5, 2, 4).contiguous().view(B, C * 4, H // 2, W // 2)
+    xd = nhwc(x, dtype, 1).requires_grad_(True)
+    y = NN.space_to_depth(xd)
+    assert y.shape == (B, H // 2, W // 2, 4 * C) and torch.equal(nchw(y, 4 * C), ref)
+    gy = torch.randn(y.shape, generator=g).to(dtype).to(dev)
+    y.backward(gy)
+    assert torch.equal(xd.grad, NN.depth_to_space(gy))                                   # the backward IS the inverse permutation
+    z = NN.depth_to_space(y.detach())
+    assert torch.equal(z, xd.detach())
+    ps = F.pixel_shuffle(ref, 2)
+    assert torch.equal(nchw(NN.depth_to_space(nhwc(ref, dtype, 1)), C), ps)
+    with pytest.raises(Exception):
+        NN.space_to_depth(torch.zeros(1, 5, 6, 16, device=dev, dtype=dtype))            # odd height
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("add,with_inv,with_p1", [(False, True, True), (False, False, True), (True, True, True), (True, False, True), (False, True, False)])
+def test_concat_with_upsampled_inverse_depth(NN, dtype, add, with_inv, with_p1):
+    """PackNet01.py:L150-199: cat([unpacked, skip(, nearest_x2(inv depth))], 1) / [unpacked + skip(, ...)] in one pass, zero-filled to the 16-byte group;
+    backward = slices and the 2x2 sums of the inverse-depth channel."""
+    g = torch.Generator().manual_seed(41)
+    V = 4 if dtype == torch.float32 else 8
+    B, H, W, C0 = 2, 8, 12, 16
+    C1 = C0 if add else 24
+    p0 = torch.randn(B, C0, H, W, generator=g).to(dtype).float()
+    p1 = torch.randn(B, C1, H, W, generator=g).to(dtype).float() if with_p1 else None
+    inv = torch.rand(B, H // 2, W // 2, generator=g) if with_inv else None
+    p0r = p0.clone().requires_grad_(True); p1r = p1.clone().requires_grad_(True) if with_p1 else None
+    invr = inv.clone().requires_grad_(True) if with_inv else None
+    parts = [p0r + p1r] if add else ([p0r, p1r] if with_p1 else [p0r])
+    if with_inv:
+        parts.append(F.interpolate(invr.unsqueeze(1), scale_factor=2, mode="nearest").to(dtype).float())
+    ref = torch.cat(parts, 1)
+    if add and dtype != torch.float32:
+        ref = ref + (ref.detach().to(dtype).float() - ref.detach())
+    p0d = nhwc(p0, dtype, V).requires_grad_(True); p1d = nhwc(p1, dtype, V).requires_grad_(True) if with_p1 else None
+    invd = inv.clone().to(dev).requires_grad_(True) if with_inv else None
+    out = NN.concat(p0d, p1d, invd, add=add)
+    Cu = ref.shape[1]
+    assert out.shape[3] == (Cu + V - 1) // V * V and (out[..., Cu:] == 0).all()
+    check(nchw(out, Cu), ref.detach(), dtype, "concat", 1e-6, 8e-3)
+    go = torch.randn(B, out.shape[3], H, W, generator=g).to(dtype).float()
+    ref.backward(go[:, :Cu])
+    out.backward(go.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev))
+    check(nchw(p0d.grad, C0), p0r.grad, dtype, "d p0", 1e-6, 1e-6)
+    if with_p1:
+        check(nchw(p1d.grad, C1), p1r.grad, dtype, "d p1", 1e-6, 1e-6)
+    if with_inv:
+        check(invd.grad.cpu(), invr.grad, dtype, "d inv", 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("flip", [False, True])
+def test_inv_depth_head(NN, dtype, flip):
+    """layers01.py:L105-133 (sigmoid / min_depth) + PackNet01.py:L120-123,L199 (disp_to_depth, flip back) in one kernel, both outputs with gradients."""
+    g = torch.Generator().manual_seed(42)
+    B, H, W, ld = 2, 6, 10, (4 if dtype == torch.float32 else 8)
+    y = torch.zeros(B, H, W, ld)
+    y[..., 0] = (torch.randn(B, H, W, generator=g) * 2).to(dtype).float()
+    yr = y[..., 0].clone().requires_grad_(True)
+    inv_r = torch.sigmoid(yr) / 0.5
+    dep_r = 1.0 / (1.0 / 80.0 + (1.0 / 0.1 - 1.0 / 80.0) * inv_r.unsqueeze(1))
+    if flip:
+        dep_r = dep_r.flip(3)
+    yd = y.to(dtype).to(dev).requires_grad_(True)
+    inv, dep = NN.inv_depth_head(yd, 0.5, 0.1, 80.0, flip)
+    assert inv.shape == (B, H, W) and dep.shape == (B, 1, H, W) and inv.dtype == torch.float32
+    check(inv.cpu(), inv_r.detach(), torch.float32, "inv", 1e-6)
+    check(dep.cpu(), dep_r.detach(), torch.float32, "depth", 2e-6)
+    gi = torch.randn(B, H, W, generator=g); gd = torch.randn(B, 1, H, W, generator=g)
+    (inv_r * gi).sum().add((dep_r * gd).sum()).backward()
+    (inv * gi.to(dev)).sum().add((dep * gd.to(dev)).sum()).backward()
+    check(yd.grad[..., 0].float().cpu(), yr.grad, dtype, "d logit", 2e-5, 8e-3)
+    assert (yd.grad[..., 1:] == 0).all()
+    # one of the two outputs unused (the finest level's inverse depth has no consumer)
+    yd2 = y.to(dtype).to(dev).requires_grad_(True)
+    _, dep2 = NN.inv_depth_head(yd2, 0.5, 0.1, 80.0, flip)
+    (dep2 * gd.to(dev)).sum().backward()
+    yr2 = y[..., 0].clone().requires_grad_(True)
+    d2 = 1.0 / (1.0 / 80.0 + (1.0 / 0.1 - 1.0 / 80.0) * (torch.sigmoid(yr2) / 0.5).unsqueeze(1))
+    ((d2.flip(3) if flip else d2) * gd).sum().backward()
+    check(yd2.grad[..., 0].float().cpu(), yr2.grad, dtype, "d logit (depth only)", 2e-5, 8e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("C", [64, 256])
+def test_group_norm_elu_with_residual(NN, dtype, C):
+    """layers01.py:L74-76 ResidualConv: ELU(GroupNorm(x_out + shortcut)) with the sum formed inside the GroupNorm kernels (fp32), gradient to both inputs."""
+    g = torch.Generator().manual_seed(43 + C)
+    B, H, W = 2, 9, 14
+    x = torch.randn(B, C, H, W, generator=g).to(dtype).float(); r = (torch.randn(B, C, H, W, generator=g) * 0.7).to(dtype).float()
+    gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.2
+    xr, rr, gr, br = (t.clone().requires_grad_(True) for t in (x, r, gamma, beta))
+    ref = F.elu(F.group_norm(xr + rr, 16, gr, br, 1e-5))
+    go = torch.randn(ref.shape, generator=g).to(dtype).float()
+    ref.backward(go)
+    V = 4 if dtype == torch.float32 else 8
+    xd = nhwc(x, dtype, V).requires_grad_(True); rd = nhwc(r, dtype, V).requires_grad_(True)
+    gd, bd = gamma.clone().to(dev).requires_grad_(True), beta.clone().to(dev).requires_grad_(True)
+    out = NN.group_norm_relu(xd, gd, bd, 16, 1e-5, "elu", residual=rd)
+    check(nchw(out, C), ref.detach(), dtype, "gn(x + r)")
+    out.backward(nhwc(go, dtype, V))
+    check(nchw(xd.grad, C), xr.grad, dtype, "dx", 5e-5, 3e-2)
+    assert torch.equal(xd.grad, rd.grad)
+    check(gd.grad.cpu(), gr.grad, dtype, "dgamma", 5e-5, 3e-2)
+    check(bd.grad.cpu(), br.grad, dtype, "dbeta", 5e-5, 3e-2)
+
+
 def test_full_size_conv_properties(NN):
     """BASELINE size (B=12, 48x160, 64->64 3x3, bf16): linearity in the input and agreement of a strided sub-sample with fp32 CPU."""
     g = torch.Generator().manual_seed(5)
