@@ -66,6 +66,30 @@ def build(args, device):
     return cfg, model, trainer
 
 
+def host_loader(arch, B, H, W, seed, steps):
+    """--with-loader: what a KITTI data loader with the ON_DEVICE preprocess chain hands over per step -- uint8 camera frames at source size
+    (375 x 1242), stacked per entry and pinned (the collator's and the pin-memory thread's work), the drawn colour-jitter parameters, and the small
+    fp32 entries (intrinsics / sparse depth) -- yielded `steps` times.  Decoding PNGs is the workers' job and not part of this measurement; the
+    host-to-device copies, the resize + colour-jitter kernels and the copy into the graph's static inputs are."""
+    import numpy as np
+    from simpledepthestimation_amd.data.synthetic import mono_batch, sup_batch
+    rng = np.random.default_rng(seed)
+    Hs, Ws = 375, 1242
+    small = sup_batch(B, H, W, seed) if arch == "SupDepthModel" else mono_batch(B, H, W, seed)
+    frames = lambda: torch.from_numpy(rng.integers(0, 256, (B, Hs, Ws, 3), dtype=np.uint8)).pin_memory()
+    params = []
+    for _ in range(B):
+        params.append([float(rng.uniform(0.8, 1.2)), float(rng.uniform(0.8, 1.2)), float(rng.uniform(0.8, 1.2)), float(rng.uniform(-0.05, 0.05))] + [float(i) for i in rng.permutation(4)])
+    batch = {"img_u8": frames(), "aug_params": torch.tensor(params, dtype=torch.float32).pin_memory(), "device_resize": (H, W)}
+    if arch == "SupDepthModel":
+        batch["depth"] = small["depth"].pin_memory()
+    else:
+        batch["ctx_img_u8"] = [frames(), frames()]
+        batch["intrinsics"] = small["intrinsics"].pin_memory()
+    nbytes = sum(t.numel() * t.element_size() for v in batch.values() for t in (v if isinstance(v, list) else [v]) if torch.is_tensor(t))
+    return (dict(batch) for _ in range(steps)), nbytes
+
+
 def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50", step_ms=None):
     """Event-instrumented eager steps of the same workload: per GEMM launch (kind, tile variant) duration and algorithmic FLOPs.
 
@@ -343,6 +367,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = physical cores of one socket (SURVEY.md 8d)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-loader", action="store_true", help="feed every step from pinned uint8 host frames through DevicePrefetcher + the device resize / "
+                    "colour-jitter kernels (the input side inside the timed region) instead of device-resident inputs")
     ap.add_argument("--force-overlap", action="store_true", help="use the two-phase backward (all-reduce overlap path) even on one GPU")
     ap.add_argument("--no-side-stream", action="store_true", help="weight-gradient GEMMs on the main stream (single-stream graph: profiling aid)")
     ap.add_argument("--no-pose-stream", action="store_true", help="MonoDepth2: PoseNet on the main stream, after the depth network (A/B aid)")
@@ -396,15 +422,36 @@ def main():
     cfg, model, trainer = build(args, device)
     batch = synth_batch(WORKLOADS[args.workload]["arch"], args.batch, args.height, args.width, 1000 + rank, device)
 
-    for _ in range(args.warmup):
-        losses = trainer.step(batch)
+    h2d_bytes = 0
+    if args.with_loader:
+        # the input side inside the timed region: pinned uint8 host batches -> DevicePrefetcher (copy stream) -> sde_image_prep_u8 -> trainer.step
+        from simpledepthestimation_amd.data import DevicePrefetcher
+        from simpledepthestimation_amd.data.device_aug import DeviceImageAug
+        arch = WORKLOADS[args.workload]["arch"]
+        # the prefetcher uploads (copy stream, persistent slot buffers); the resize + jitter kernels run at the head of the step and write the graph's
+        # static inputs in place (measured both ways: the kernels on the copy stream + device-to-device copies into the static inputs cost 8-15 %)
+        trainer.input_transform = DeviceImageAug(device)
+        gen, h2d_bytes = host_loader(arch, args.batch, args.height, args.width, 2000 + rank, max(args.warmup, 4))
+        feed = DevicePrefetcher(gen, device)        # ONE prefetcher for warm-up and timed region: its slot buffers are allocated during the warm-up
+        for hb in feed:
+            losses = trainer.step(hb)
+    else:
+        for _ in range(args.warmup):
+            losses = trainer.step(batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if args.with_loader:
+        gen, _ = host_loader(arch, args.batch, args.height, args.width, 3000 + rank, args.steps)
+        feed.loader = gen
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = trainer.step(batch)
+    if args.with_loader:
+        for hb in feed:
+            losses = trainer.step(hb)
+    else:
+        for _ in range(args.steps):
+            losses = trainer.step(batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -431,6 +478,9 @@ def main():
                "backend": ("none" if world == 1 else {"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend())),
                "rccl_ranks": (world if world > 1 and dist.get_backend() == "nccl" else 0), "devices": min(world, ndev),
                "final_losses": final}
+        if args.with_loader:
+            out["data"] = "synthetic uint8 frames at 375x1242 fed per step through the pinned host -> device prefetcher and the device resize + colour-jitter kernels"
+            out["input_side"] = {"h2d_bytes_per_step": h2d_bytes, "in_timed_region": True}
         if args.profile_steps > 0:
             hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype, args.workload, step_ms=ms)
             if hbm is not None:

@@ -378,6 +378,18 @@ int sde_loss_scale_update(float* scale_state, float growth_factor, float backoff
 
 
 /* ---------------------------------------------------------------------------------------------------
+ * Device-side input pipeline: N uint8 frames [N][Hs][Ws][3] of ONE source size -> the resized (h x w), colour-jittered frame and
+ * the resized un-jittered frame as fp32 NCHW in [0, 1] (`img` / `img_orig`, `ctx_img` / `ctx_img_orig` of the batch dict), replacing the CPU chain
+ * Resize -> RandomImageAug -> ToTensor of detectron2/data/preprocess/augmentation.py:L124-166,L229-266 for the image entries, in the same integer /
+ * float32 arithmetic (OpenCV's fixed-point INTER_LINEAR; Pillow's Image.blend / L / HSV conversions), i.e. bit-identical to this package's CPU chain.
+ * xtab [w][4] = (x0, x1, a0, a1), ytab [h][4] = (y0, y1, b0, b1): OpenCV's source taps and 11-bit weights per output column / row (device, 16-byte
+ * aligned; data/device_aug.py builds them once per size pair).  jit [N][8] (device): brightness, contrast, saturation, hue factor, then the order of
+ * the four steps (0 brightness, 1 contrast, 2 saturation, 3 hue) as floats; jit[n][4] < 0: frame n is not jittered.  lsum [N]: workspace.
+ * orig may be NULL.  Two launches (the contrast step needs the frame's mean luminance at that point of the chain), no host synchronisation. */
+int sde_image_prep_u8(const uint8_t* src, int N, int Hs, int Ws, int h, int w, const int* xtab, const int* ytab, const float* jit, unsigned* lsum, float* img,
+                      float* orig, sde_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Evaluation: detectron2/evaluation/depth_evaluation.py:L74-104 kitti_evaluator.process for ONE image, with
  * compute_errors (L30-53), garg_crop / eigen_crop (L16-27, as the window [y0,y1) x [x0,x1) in gt coordinates), the 1e-3 < gt < 80 median
  * scaling of TEST.GT_SCALE (L91-93) and the postprocess.backward() chain folded into two index maps: ymap[gh], xmap[gw] give the

@@ -130,54 +130,86 @@ def build_detection_test_loader(cfg):
 
 
 class DevicePrefetcher:
-    """Wraps a loader: batch k+1 is pinned and copied host -> device on a copy stream while step k runs; __next__ makes the consumer's
-    stream wait on the copy's event (no host synchronisation).  Arrays (tensors, numpy arrays, lists of them) move; everything else
-    (flip, metadata) passes through.  len() and re-iteration follow the wrapped loader."""
+    """Wraps a loader: batch k+1 is copied host -> device on a copy stream while step k runs; __next__ makes the consumer's stream wait on the copy's
+    event (no host synchronisation).  Arrays (tensors, numpy arrays, lists of them) move; everything else (flip, metadata) passes through.  len() and
+    re-iteration follow the wrapped loader.
 
-    def __init__(self, loader, device):
+    The device side is a ring of `slots` persistent buffer sets (static shapes: what the captured hipGraph needs, too): entry `k` of a batch lands in
+    the same device tensor every `slots` batches, so the steady state allocates nothing -- per-step allocations on a side stream make the caching
+    allocator wait for (or hipMalloc around) blocks the main stream still uses, and the host ends up pacing the GPU (measured: 7.6 ms of host time
+    per 6.6 ms step).  A slot is rewritten only behind the event the consumer's stream recorded when it came back for the NEXT batch, i.e. after
+    everything it enqueued on that slot's tensors -- which is why a yielded batch is valid until the iterator is advanced `slots - 1` more times.
+    device_aug: optional callable(batch, buffers) run on the copy stream right behind the uploads (data/device_aug.py: DeviceImageAug turns the raw
+    uint8 frames of the ON_DEVICE preprocess chain into the fp32 image entries).  Without it the raw entries are uploaded like any other array and
+    the consumer transforms them -- HipTrainer.input_transform = DeviceImageAug(...) runs the kernels at the head of the step, straight into the
+    captured graph's static inputs; that is the faster arrangement on this stack (bench.py --with-loader; DESIGN.md: measured both ways)."""
+
+    _RAW = ("img_u8", "ctx_img_u8", "aug_params", "device_resize")     # consumed by device_aug (which uploads them itself)
+
+    def __init__(self, loader, device, device_aug=None, slots=3):
         self.loader, self.device = loader, torch.device(device)
+        self.device_aug = device_aug
         self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._slots = max(2, int(slots))
+        self._bufs = [dict() for _ in range(self._slots)]      # per slot: key -> persistent device tensor
+        self._release = [None] * self._slots                  # per slot: event on the consumer's stream behind its last use
 
     def __len__(self):
         return len(self.loader)
 
-    def _move(self, v):
+    def _into(self, bufs, key, v):
+        """Copy host / device tensor v into the slot's persistent buffer for `key` (re-created when the shape or dtype changes)."""
         if isinstance(v, np.ndarray):
             v = torch.from_numpy(np.ascontiguousarray(v))
-        if torch.is_tensor(v):
-            if self._stream is not None and v.device.type == "cpu":
-                v = v.pin_memory()
-            return v.to(self.device, non_blocking=True)
+        b = bufs.get(key)
+        if b is None or b.shape != v.shape or b.dtype != v.dtype:
+            b = bufs[key] = torch.empty(v.shape, dtype=v.dtype, device=self.device)
+        if v.device.type == "cpu" and not v.is_pinned():
+            v = v.pin_memory()
+        b.copy_(v, non_blocking=True)
+        return b
+
+    def _move(self, bufs, key, v):
+        if isinstance(v, np.ndarray) or torch.is_tensor(v):
+            return self._into(bufs, key, v) if self._stream is not None else torch.as_tensor(v).to(self.device)
         if isinstance(v, (list, tuple)) and v and all(isinstance(x, np.ndarray) or torch.is_tensor(x) for x in v):
-            return [self._move(x) for x in v]
+            return [self._move(bufs, (key, i), x) for i, x in enumerate(v)]
         return v
 
-    def _stage(self, batch):
+    def _stage(self, batch, slot):
         if self._stream is None:
-            return {k: self._move(v) for k, v in batch.items()}, None
+            out = {k: self._move(None, k, v) for k, v in batch.items()}
+            return (self.device_aug(out) if self.device_aug is not None else out), None
+        bufs = self._bufs[slot]
         with torch.cuda.stream(self._stream):
-            out = {k: self._move(v) for k, v in batch.items()}
+            if self._release[slot] is not None:
+                self._stream.wait_event(self._release[slot])      # the consumer is done with this slot's tensors
+            out = {k: (v if (self.device_aug is not None and k in self._RAW) else self._move(bufs, k, v)) for k, v in batch.items()}
+            if self.device_aug is not None:
+                out = self.device_aug(out, bufs)
             ev = torch.cuda.Event()
             ev.record(self._stream)
         return out, ev
 
     def __iter__(self):
         it = iter(self.loader)
-        nxt = None
+        nxt, n = None, 0
         try:
-            nxt = self._stage(next(it))
+            nxt = self._stage(next(it), 0)
         except StopIteration:
             return
         while nxt is not None:
             cur, ev = nxt
+            slot = n % self._slots
+            n += 1
             try:
-                nxt = self._stage(next(it))
+                nxt = self._stage(next(it), n % self._slots)
             except StopIteration:
                 nxt = None
             if ev is not None:
                 torch.cuda.current_stream(self.device).wait_event(ev)
-                for v in cur.values():              # the tensors were allocated on the copy stream: tell the allocator who uses them now
-                    for t in (v if isinstance(v, list) else [v]):
-                        if torch.is_tensor(t) and t.is_cuda:
-                            t.record_stream(torch.cuda.current_stream(self.device))
             yield cur
+            if ev is not None:                      # the consumer came back: everything it enqueued on this slot's tensors is behind this event
+                rel = torch.cuda.Event()
+                rel.record(torch.cuda.current_stream(self.device))
+                self._release[slot] = rel

@@ -173,6 +173,16 @@ class KittiDepthV2(DatasetBase):
                 ret[key] = [arr[:, i] for i in range(arr.shape[1])]
             elif key == "flip":
                 ret[key] = value[0]
+            elif key == "aug_params":
+                ret[key] = torch.from_numpy(np.stack(value, 0))
             else:
                 ret[key] = value
+        if "img_u8" in merged:
+            # ON_DEVICE chain (an addition of this package): when every frame of the batch has one source size they are stacked here, in the worker, so
+            # that the loader's pin-memory thread pins ONE tensor per entry and data/device_aug.py uploads each with one copy; otherwise per-frame lists
+            shapes = {v.shape for v in merged["img_u8"]} | {a.shape for v in merged.get("ctx_img_u8", []) for a in v}
+            if len(shapes) == 1:
+                ret["img_u8"] = torch.from_numpy(np.stack(merged["img_u8"], 0))
+                if "ctx_img_u8" in merged:
+                    ret["ctx_img_u8"] = [torch.from_numpy(np.stack([v[i] for v in merged["ctx_img_u8"]], 0)) for i in range(len(merged["ctx_img_u8"][0]))]
         return ret

@@ -126,13 +126,24 @@ def resize_nearest(arr, dst_w, dst_h):
 
 @PREPROCESS_REGISTRY.register()
 class Resize(Preprocess):
+    """ON_DEVICE: True (an addition of this package) leaves the uint8 frames at their source size -- the device pipeline (data/device_aug.py,
+    sde_image_prep_u8) resizes them with the same fixed-point rule after the host-to-device copy -- and still rescales the intrinsics, the sparse
+    depth and the masks here (they are small and stay on the host path)."""
+
     def __init__(self, cfg):
         super().__init__(cfg)
         self.img_h, self.img_w = cfg.IMG_H, cfg.IMG_W
+        self.on_device = bool(cfg.get("ON_DEVICE", False))
 
     def forward(self, data_dict):
         H, W, _ = data_dict["img"].shape
+        if self.on_device:
+            data_dict["device_resize"] = (self.img_h, self.img_w)
+            return self._forward_rest(data_dict, H, W, images=False)
         data_dict["img"] = resize_linear_u8(data_dict["img"], self.img_w, self.img_h)
+        return self._forward_rest(data_dict, H, W, images=True)
+
+    def _forward_rest(self, data_dict, H, W, images):
         if "intrinsics" in data_dict:
             K = data_dict["intrinsics"]
             K[0, 0] *= self.img_w / W; K[0, 2] *= self.img_w / W
@@ -141,7 +152,7 @@ class Resize(Preprocess):
             data_dict["depth"] = resize_depth(data_dict["depth"], (self.img_h, self.img_w))
         if "mask" in data_dict:
             data_dict["mask"] = resize_nearest(data_dict["mask"], self.img_w, self.img_h)
-        if "ctx_img" in data_dict:
+        if images and "ctx_img" in data_dict:
             data_dict["ctx_img"] = [resize_linear_u8(a, self.img_w, self.img_h) for a in data_dict["ctx_img"]]
         if "ctx_depth" in data_dict:
             data_dict["ctx_depth"] = [resize_depth(d, (self.img_h, self.img_w)) for d in data_dict["ctx_depth"]]
@@ -234,6 +245,7 @@ class RandomImageAug(Preprocess):
         self.contrast = [max(1 - float(p[1]), 0.0), 1 + float(p[1])]
         self.saturation = [max(1 - float(p[2]), 0.0), 1 + float(p[2])]
         self.hue = [-float(p[3]), float(p[3])]
+        self.on_device = bool(cfg.get("ON_DEVICE", False))
         self.fn_idx = self.b = self.c = self.s = self.h = None
         self.get_params()
 
@@ -259,6 +271,19 @@ class RandomImageAug(Preprocess):
         return img
 
     def forward(self, data_dict):
+        if self.on_device:
+            # ON_DEVICE: True (an addition of this package): draw the SAME random numbers in the same order and hand the raw uint8 frames plus the
+            # parameters to the device pipeline (data/device_aug.py), which produces img / img_orig / ctx_img / ctx_img_orig after the copy to HBM
+            params = np.array([1.0, 1.0, 1.0, 0.0, -1.0, -1.0, -1.0, -1.0], dtype=np.float32)
+            if random.random() < self.jitter_prob:
+                self.get_params()
+                params = np.array([self.b, self.c, self.s, self.h] + [float(i) for i in self.fn_idx], dtype=np.float32)
+            data_dict["img_u8"] = np.ascontiguousarray(data_dict.pop("img"))
+            if "ctx_img" in data_dict:
+                data_dict["ctx_img_u8"] = [np.ascontiguousarray(a) for a in data_dict.pop("ctx_img")]
+            data_dict["aug_params"] = params
+            data_dict.setdefault("device_resize", tuple(data_dict["img_u8"].shape[:2]))
+            return data_dict
         from PIL import Image
         data_dict["img_orig"] = data_dict["img"].copy()
         if "ctx_img" in data_dict:

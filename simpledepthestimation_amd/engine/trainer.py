@@ -145,6 +145,9 @@ class HipTrainer:
         self._graphs = {}
         self._static_batch = None
         self._static_out = None
+        # optional callable(batch, static_batch_or_None) -> batch run at the head of every step on the step's stream: data/device_aug.py's DeviceImageAug
+        # turns uploaded uint8 frames into the fp32 image entries there, writing straight into the captured graph's static inputs
+        self.input_transform = None
         self._packer = None            # built lazily after the first eager step (needs the operand shapes seen in forward)
         self._one = None
         self.batch_pack = adam_fn is None
@@ -366,12 +369,15 @@ class HipTrainer:
         for k, v in batch.items():
             s, kind = self._static_batch[k], self._kind(v)
             if kind == "array":
+                if torch.is_tensor(v) and v is s:
+                    continue                       # written in place by input_transform
                 s.copy_(self._staged(v), non_blocking=True)
             elif kind == "arrays":
                 if len(s) != len(v):
                     raise RuntimeError(f"batch entry '{k}' changed length ({len(s)} -> {len(v)})")
                 for a, b in zip(s, v):
-                    a.copy_(self._staged(b), non_blocking=True)
+                    if not (torch.is_tensor(b) and b is a):
+                        a.copy_(self._staged(b), non_blocking=True)
             else:
                 self._static_batch[k] = v          # steering scalars are part of the graph key; opaque entries are not read by captured work
 
@@ -417,6 +423,8 @@ class HipTrainer:
 
     def step(self, batch):
         """One optimisation step.  Returns {loss name: 0-d device tensor} (no host sync)."""
+        if self.input_transform is not None:
+            batch = self.input_transform(batch, None, self._static_batch if self.use_graph else None)
         if self.use_graph:
             hit = self._graphs.get(self._graph_key(batch)) if self._static_batch is not None else None
             if hit is None:

@@ -1,0 +1,178 @@
+"""Device-side image pipeline (csrc/imageprep.hip, data/device_aug.py) against this package's CPU chain Resize -> RandomFlip -> RandomImageAug -> ToTensor
+(reference: detectron2/data/preprocess/augmentation.py:L124-166,L229-266, formating.py:L8-21).
+
+CPU part: the integer / float32 colour arithmetic the kernel implements, restated in numpy, equals Pillow (the library the CPU chain calls) on random and
+boundary triples; the ON_DEVICE flavour of the preprocess steps draws the same random numbers as the CPU steps.  GPU part: bit-identical batch entries."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from simpledepthestimation_amd.data.preprocess import build_preprocess
+
+
+def _blend(d, x, f):
+    f = np.float32(f)
+    t = (d.astype(np.float32) + f * (x.astype(np.float32) - d.astype(np.float32))).astype(np.float32)
+    if 0.0 <= float(f) <= 1.0:
+        return t.astype(np.uint8)
+    return np.clip(t, 0, 255).astype(np.uint8)
+
+
+def _lum(rgb):
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def _rgb2hsv(rgb):
+    r, g, b = (rgb[..., i].astype(np.int32) for i in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = (cr / maxc.astype(np.float32)).astype(np.float32)
+        rc, gc, bc = (((maxc - c).astype(np.float32) / cr).astype(np.float32).astype(np.float64) for c in (r, g, b))
+        h = np.where(r == maxc, bc - gc, np.where(g == maxc, 2.0 + rc - bc, 4.0 + gc - rc)).astype(np.float32).astype(np.float64)
+        h = np.fmod(h / 6.0 + 1.0, 1.0).astype(np.float32).astype(np.float64)
+        uh = np.clip(np.nan_to_num(h * 255.0).astype(np.int64), 0, 255)
+        us = np.clip(np.nan_to_num(s.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    eq = minc == maxc
+    return np.stack([np.where(eq, 0, uh), np.where(eq, 0, us), maxc], -1).astype(np.uint8)
+
+
+def _hsv2rgb(hsv):
+    h = hsv[..., 0].astype(np.float32).astype(np.float64)
+    s, v = hsv[..., 1], hsv[..., 2]
+    hv = h * 6.0 / 255.0
+    i = np.floor(hv).astype(np.int64)
+    f = (hv - i.astype(np.float32).astype(np.float64)).astype(np.float32).astype(np.float64)
+    fs = (s.astype(np.float32).astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)
+    vf = v.astype(np.float32).astype(np.float64)
+    rnd = lambda x: np.floor(x + 0.5).astype(np.int64)          # C round() on non-negative values
+    p, q, t = (np.clip(rnd(vf * e), 0, 255) for e in (1.0 - fs, 1.0 - fs * f, 1.0 - fs * (1.0 - f)))
+    vi, k = v.astype(np.int64), i % 6
+    out = np.stack([np.choose(k, [vi, q, p, p, t, vi]), np.choose(k, [t, vi, vi, q, p, p]), np.choose(k, [p, p, t, vi, vi, q])], -1)
+    return np.where((s == 0)[..., None], np.stack([vi, vi, vi], -1), out).astype(np.uint8)
+
+
+def test_restated_colour_arithmetic_equals_pillow():
+    """What csrc/imageprep.hip computes per pixel (Image.blend, the L conversion, RGB <-> HSV of Pillow's Convert.c), restated in numpy with the
+    same float32 / float64 steps, against Pillow itself: exact on 2^20 random triples plus the grey / saturated boundaries.  (The full 2^24 cube was
+    checked when the kernel was written: 0 mismatches both ways.)"""
+    from PIL import Image, ImageEnhance, ImageStat
+    rng = np.random.default_rng(7)
+    rgb = rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    rgb[0, :256] = np.arange(256, dtype=np.uint8)[:, None]                    # greys
+    rgb[1, :256, 0], rgb[1, :256, 1], rgb[1, :256, 2] = 255, np.arange(256), 0
+    im = Image.fromarray(rgb)
+    assert np.array_equal(np.array(im.convert("L")), _lum(rgb))
+    hsv = np.array(im.convert("HSV"))
+    assert np.array_equal(hsv, _rgb2hsv(rgb))
+    assert np.array_equal(np.array(Image.fromarray(hsv, "HSV").convert("RGB")), _hsv2rgb(hsv))
+    any_hsv = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    assert np.array_equal(np.array(Image.fromarray(any_hsv, "HSV").convert("RGB")), _hsv2rgb(any_hsv))
+    small = rgb[:96, :128]
+    ims = Image.fromarray(small)
+    mean = int(ImageStat.Stat(ims.convert("L")).mean[0] + 0.5)
+    assert mean == int(_lum(small).astype(np.int64).sum() / _lum(small).size + 0.5)
+    for f in (0.8, 0.97, 1.0, 1.13, 1.2):
+        assert np.array_equal(np.array(ImageEnhance.Brightness(ims).enhance(f)), _blend(np.zeros_like(small), small, f))
+        assert np.array_equal(np.array(ImageEnhance.Contrast(ims).enhance(f)), _blend(np.full_like(small, mean), small, f))
+        assert np.array_equal(np.array(ImageEnhance.Color(ims).enhance(f)), _blend(np.repeat(_lum(small)[..., None], 3, 2), small, f))
+
+
+def _chain(on_device, h=16, w=40, jitter_prob=1.0):
+    extra = {"ON_DEVICE": True} if on_device else {}
+    return [build_preprocess(dict(NAME="Resize", IMG_H=h, IMG_W=w, **extra)), build_preprocess(dict(NAME="RandomFlip")),
+            build_preprocess(dict(NAME="RandomImageAug", JITTER_PROB=jitter_prob, **extra)), build_preprocess(dict(NAME="ToTensor"))]
+
+
+def _sample(rng, Hs, Ws, nctx):
+    d = {"img": rng.integers(0, 256, (Hs, Ws, 3), dtype=np.uint8), "intrinsics": np.array([[700.0, 0, Ws / 2], [0, 710.0, Hs / 2], [0, 0, 1]], np.float32),
+         "metadata": {}}
+    if nctx:
+        d["ctx_img"] = [rng.integers(0, 256, (Hs, Ws, 3), dtype=np.uint8) for _ in range(nctx)]
+    return d
+
+
+def _run(chain, sample, seed):
+    random.seed(seed); torch.manual_seed(seed); np.random.seed(seed)
+    d = {k: ([a.copy() for a in v] if isinstance(v, list) else (v.copy() if isinstance(v, np.ndarray) else dict(v))) for k, v in sample.items()}
+    for p in chain:
+        d = p.forward(d)
+    return d
+
+
+def test_on_device_chain_draws_the_same_random_numbers_and_keeps_the_small_entries():
+    rng = np.random.default_rng(3)
+    s = _sample(rng, 37, 124, 2)
+    for seed in range(6):
+        cpu, devc = _run(_chain(False), s, seed), _run(_chain(True), s, seed)
+        assert cpu["flip"] == devc["flip"] and np.array_equal(cpu["intrinsics"], devc["intrinsics"]) and cpu["metadata"] == devc["metadata"]
+        assert "img" not in devc and devc["img_u8"].shape == (37, 124, 3) and len(devc["ctx_img_u8"]) == 2 and tuple(devc["device_resize"]) == (16, 40)
+        aug = _chain(False)[2]
+        random.seed(seed); torch.manual_seed(seed)
+        _ = random.random() > 0.5                                     # RandomFlip's draw
+        assert random.random() < 1.0
+        aug.get_params()
+        assert np.allclose(devc["aug_params"], [aug.b, aug.c, aug.s, aug.h] + [float(i) for i in aug.fn_idx], rtol=0, atol=0)
+    off = _run(_chain(True, jitter_prob=0.0), s, 1)
+    assert off["aug_params"][4] < 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nctx", [0, 2])
+def test_device_pipeline_equals_the_cpu_chain_bit_for_bit(nctx):
+    """sde_image_prep_u8 (fixed-point resize + the four jitter steps in any order + / 255) vs Resize -> RandomImageAug -> ToTensor on the host: every
+    batch entry identical, for frames of two source sizes in one batch, all orders that 12 seeds draw, and un-jittered samples."""
+    from simpledepthestimation_amd.data.device_aug import DeviceImageAug
+    rng = np.random.default_rng(11)
+    aug = DeviceImageAug("cuda")
+    orders = set()
+    for seed in range(12):
+        sizes = [(37, 124), (37, 124), (36, 122), (37, 124)]
+        prob = 1.0 if seed % 4 else 0.5
+        samples = [_sample(rng, Hs, Ws, nctx) for Hs, Ws in sizes]
+        cpu = [_run(_chain(False, jitter_prob=prob), s, 100 * seed + i) for i, s in enumerate(samples)]
+        raw = [_run(_chain(True, jitter_prob=prob), s, 100 * seed + i) for i, s in enumerate(samples)]
+        orders.update(tuple(r["aug_params"][4:].astype(int)) for r in raw)
+        batch = {"img_u8": [r["img_u8"] for r in raw], "aug_params": [r["aug_params"] for r in raw], "device_resize": [r["device_resize"] for r in raw],
+                 "flip": raw[0]["flip"]}
+        if nctx:
+            batch["ctx_img_u8"] = [r["ctx_img_u8"] for r in raw]
+        out = aug(batch)
+        torch.cuda.synchronize()
+        assert out["flip"] == raw[0]["flip"] and "img_u8" not in out
+        assert torch.equal(out["img"].cpu(), torch.stack([c["img"] for c in cpu])), f"seed {seed}: jittered target frames differ"
+        assert torch.equal(out["img_orig"].cpu(), torch.stack([c["img_orig"] for c in cpu]))
+        for i in range(nctx):
+            assert torch.equal(out["ctx_img"][i].cpu(), torch.stack([c["ctx_img"][i] for c in cpu])), f"seed {seed}: jittered context {i} differs"
+            assert torch.equal(out["ctx_img_orig"][i].cpu(), torch.stack([c["ctx_img_orig"][i] for c in cpu]))
+    assert len(orders) >= 6, orders
+
+
+@pytest.mark.gpu
+def test_device_pipeline_at_kitti_size_through_the_prefetcher():
+    """375 x 1242 frames -> 192 x 640 through DevicePrefetcher(device_aug=...): the entries the trainer receives equal the CPU chain's."""
+    from simpledepthestimation_amd.data import DevicePrefetcher
+    from simpledepthestimation_amd.data.device_aug import DeviceImageAug
+    rng = np.random.default_rng(5)
+    samples = [_sample(rng, 375, 1242, 2) for _ in range(2)]
+    cpu = [_run(_chain(False, 192, 640), s, 40 + i) for i, s in enumerate(samples)]
+    raw = [_run(_chain(True, 192, 640), s, 40 + i) for i, s in enumerate(samples)]
+    batch = {"img_u8": [r["img_u8"] for r in raw], "ctx_img_u8": [r["ctx_img_u8"] for r in raw], "aug_params": [r["aug_params"] for r in raw],
+             "device_resize": [r["device_resize"] for r in raw], "intrinsics": torch.from_numpy(np.stack([r["intrinsics"] for r in raw])), "flip": False}
+    got = list(DevicePrefetcher([batch], "cuda", device_aug=DeviceImageAug("cuda")))
+    torch.cuda.synchronize()
+    assert len(got) == 1 and got[0]["intrinsics"].is_cuda and got[0]["img"].shape == (2, 3, 192, 640)
+    assert torch.equal(got[0]["img"].cpu(), torch.stack([c["img"] for c in cpu])) and torch.equal(got[0]["img_orig"].cpu(), torch.stack([c["img_orig"] for c in cpu]))
+    assert torch.equal(got[0]["ctx_img"][1].cpu(), torch.stack([c["ctx_img"][1] for c in cpu]))
+    # the collated form (frames of one source size stacked by the collator, pinned by the loader): one upload and one pair of launches per entry
+    stacked = dict(batch, img_u8=torch.from_numpy(np.stack(batch["img_u8"])).pin_memory(), aug_params=torch.from_numpy(np.stack(batch["aug_params"])),
+                   ctx_img_u8=[torch.from_numpy(np.stack([r["ctx_img_u8"][i] for r in raw])).pin_memory() for i in range(2)])
+    got2 = list(DevicePrefetcher([stacked], "cuda", device_aug=DeviceImageAug("cuda")))
+    torch.cuda.synchronize()
+    for k in ("img", "img_orig"):
+        assert torch.equal(got2[0][k], got[0][k])
+    for i in range(2):
+        assert torch.equal(got2[0]["ctx_img"][i], got[0]["ctx_img"][i]) and torch.equal(got2[0]["ctx_img_orig"][i], got[0]["ctx_img_orig"][i])
