@@ -42,6 +42,7 @@ def test_python_binding_covers_header():
     except ImportError:
         pass
     import simpledepthestimation_amd.hip.evaluation  # noqa: F401
+    import simpledepthestimation_amd.data.device_aug  # noqa: F401  (sde_image_prep_u8)
     bound = set(L._PROTOS) | {"sde_last_error"}
     missing = [s for s in declared_symbols() if s not in bound]
     assert not missing, f"no ctypes prototype for: {missing}"
