@@ -59,13 +59,29 @@ template <> __device__ __forceinline__ void store_vec<half_t>(half_t* p, const f
     *reinterpret_cast<h8*>(p) = t;
 }
 
-// the 16-byte group at p plus its two neighbours along the channel axis (zero outside [0, D))
+// Value held by the previous / next lane of the wave (DPP wave_shr:1 / wave_shl:1: a VALU modifier, no LDS crossbar trip).
+__device__ __forceinline__ float lane_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// the 16-byte group at p plus its two neighbours along the channel axis (zero outside [0, D)).  Consecutive lanes hold consecutive channel groups of
+// one pixel (idx = pixel * groups + group), so the neighbour elements are the next lane's first and the previous lane's last element: two DPP moves
+// instead of two 2-byte global loads per group (the loads were two thirds of the load instructions of these kernels).  Only the first / last lane of a
+// wave can have its neighbour in another wave (more than 64 groups per pixel, or a group count that does not divide 64): those two lanes load it.
+// Lanes of one pixel take the same branches (same tap validity), so a lane that uses a neighbour's value always finds that neighbour active.
 template <typename T>
 __device__ __forceinline__ void load_with_edges(const T* p, int c0, int D, float* o /*[V+2]*/) {
     constexpr int V = VecOf<T>::V;
     load_vec<T>(p, o + 1);
-    o[0] = c0 > 0 ? (float)p[-1] : 0.f;
-    o[V + 1] = c0 + V < D ? (float)p[V] : 0.f;
+    float l = lane_prev(o[V]), r = lane_next(o[1]);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0 && c0 > 0) l = (float)p[-1];
+    if (lane == 63 && c0 + V < D) r = (float)p[V];
+    o[0] = c0 > 0 ? l : 0.f;
+    o[V + 1] = c0 + V < D ? r : 0.f;
 }
 
 struct Item { int b, y, x, c0; long pix; };
@@ -158,11 +174,14 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const T* __restrict__
 
 // part[block][f*28 + t] (t < 27: weight tap, t == 27: bias) = this workgroup's share of
 //   dw[f][kd][kh][kw] = sum dy[b,h,w,f*D+ch] * x[b,h+kh-1,w+kw-1,ch+kd-1] ;  dbias[f] = sum dy[b,h,w,f*D+ch]
-constexpr int WG_ITEMS = 8;      // (pixel, channel group) items per thread
-constexpr int WG_F = 2;          // features per pass: the 3x3 neighbourhood is re-read NF / WG_F times (registers: WG_F x 28 sums + 10 taps)
+constexpr int WG_ITEMS = 8;      // (pixel, channel group) items per thread at most; small layers take fewer so that the grid still fills the CUs
+#ifndef C3D_WG_F
+#define C3D_WG_F 4
+#endif
+constexpr int WG_F = C3D_WG_F;   // features per pass: the 3x3 neighbourhood is re-read NF / WG_F times (registers: WG_F x 28 sums + 10 taps)
 template <typename T>
 __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, int B, int H,
-                                                           int W, int D) {
+                                                           int W, int D, int items) {
     constexpr int V = VecOf<T>::V;
     __shared__ float red[4][WG_F][NT + 1];
     const long total = (long)B * H * W * (D / V);
@@ -174,8 +193,8 @@ __global__ void __launch_bounds__(256) conv3d_wgrad_kernel(const T* __restrict__
 #pragma unroll
             for (int t = 0; t <= NT; ++t) acc[f][t] = 0.f;
 #pragma unroll 1
-        for (int i = 0; i < WG_ITEMS; ++i) {
-            const long idx = ((long)blockIdx.x * WG_ITEMS + i) * 256 + threadIdx.x;
+        for (int i = 0; i < items; ++i) {
+            const long idx = ((long)blockIdx.x * items + i) * 256 + threadIdx.x;
             if (idx >= total) break;
             const Item it = decode<V>(idx, H, W, D);
             float g[WG_F][V];
@@ -285,10 +304,19 @@ int sde_conv3d_dgrad(const void* dy, const float* w, int B, int H, int W, int D,
     return SDE_OK;
 }
 
+// items per thread: 8 for the big layers (fewer partial rows), down to 1 where 8 would leave fewer than ~1024 workgroups (the 6x20 ... 24x80 levels
+// ran 23-180 workgroups of serial work: 80 us launches for 0.01 GB of data)
+static int wgrad_items(long n) {
+    long it = n / (256L * 1024);
+    return (int)(it < 1 ? 1 : (it > WG_ITEMS ? WG_ITEMS : it));
+}
+
 int sde_conv3d_wgrad_num_blocks(int B, int H, int W, int D, int dtype) {
     const int V = SDE_IS16(dtype) ? 8 : 4;
     if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || D % V) return -1;
-    return (int)((n_items(B, H, W, D, dtype) + 256 * WG_ITEMS - 1) / (256 * WG_ITEMS));
+    const long n = n_items(B, H, W, D, dtype);
+    const int items = wgrad_items(n);
+    return (int)((n + 256L * items - 1) / (256L * items));
 }
 
 int sde_conv3d_wgrad(const void* x, const void* dy, int B, int H, int W, int D, int dtype, float* part, float* dw, float* dbias, int accumulate,
@@ -297,9 +325,10 @@ int sde_conv3d_wgrad(const void* x, const void* dy, int B, int H, int W, int D, 
     if (rc) return rc;
     SDE_CHECK_ARG(part && dw, "sde_conv3d_wgrad: null pointer");
     const int nb = sde_conv3d_wgrad_num_blocks(B, H, W, D, dtype);
-    if (dtype == SDE_BF16) hipLaunchKernelGGL(conv3d_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, part, B, H, W, D);
-    else if (dtype == SDE_F16) hipLaunchKernelGGL(conv3d_wgrad_kernel<half_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy, part, B, H, W, D);
-    else hipLaunchKernelGGL(conv3d_wgrad_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, part, B, H, W, D);
+    const int items = wgrad_items(n_items(B, H, W, D, dtype));
+    if (dtype == SDE_BF16) hipLaunchKernelGGL(conv3d_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, part, B, H, W, D, items);
+    else if (dtype == SDE_F16) hipLaunchKernelGGL(conv3d_wgrad_kernel<half_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy, part, B, H, W, D, items);
+    else hipLaunchKernelGGL(conv3d_wgrad_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)dy, part, B, H, W, D, items);
     SDE_CHECK_LAUNCH("sde_conv3d_wgrad");
     hipLaunchKernelGGL(conv3d_wgrad_finalize_kernel, dim3(WG_COLS), dim3(256), 0, (hipStream_t)stream, part, nb, dw, dbias, accumulate);
     SDE_CHECK_LAUNCH("sde_conv3d_wgrad/finalize");

@@ -100,8 +100,16 @@ class HipTrainer:
         self.m = torch.zeros(total, device=dev, dtype=torch.float32)
         self.v = torch.zeros(total, device=dev, dtype=torch.float32)
         off, seg_end = 0, []
+        self._module_cuts = set()      # offsets where the top-level sub-module changes (encoder.layer3 | encoder.layer4 | decoder ...): bucket boundaries
+        prev_mod = None
         for g in self.groups:
-            for _, p in g.named_params:
+            for n_, p in g.named_params:
+                parts = n_.split(".")
+                i_layer = next((i for i, t in enumerate(parts) if t.startswith("layer") or t in ("decoder", "pose_net", "conv1", "bn1")), None)
+                mod = (g.name, ".".join(parts[:i_layer + 1]) if i_layer is not None else parts[0])
+                if mod != prev_mod:
+                    self._module_cuts.add(off)
+                    prev_mod = mod
                 self._off[id(p)] = off
                 flat_view(self.pflat, off, p).copy_(p.data)
                 p.data = flat_view(self.pflat, off, p)
@@ -293,14 +301,24 @@ class HipTrainer:
     def _backward_rest(self):
         self._backward(self._cut.backward_rest)
 
-    def _allreduce(self, lo=0, hi=None, wait=True):
+    def bucket_ranges(self, lo=0, hi=None, reverse=False):
+        """The slices of gflat[lo:hi] that travel as one all-reduce each: cut at the parameter-group boundaries and at the top-level module
+        boundaries inside a group (decoder | layer4 | layer3 | ...), then at bucket_mb.  reverse=True yields them last-created first -- the order in
+        which backward finalises them and the order DDP's reducer sends its buckets (detectron2/utils/setup.py:L38-45 wraps the reference in DDP)."""
+        hi = self.numel if hi is None else hi
+        per = self.buckets[0][1] - self.buckets[0][0]
+        cuts = sorted({c for c in self._module_cuts if lo < c < hi} | {lo, hi})
+        out = []
+        for a, b in zip(cuts, cuts[1:]):
+            out += [(s, min(b, s + per)) for s in range(a, b, per)]
+        return out[::-1] if reverse else out
+
+    def _allreduce(self, lo=0, hi=None, wait=True, reverse=False):
         """SUM all-reduce of gflat[lo:hi] in buckets; returns the work handles (already waited on unless wait=False)."""
         if self.world == 1:
             return []
-        hi = self.numel if hi is None else hi
         handles = []
-        for a, b in self.buckets:
-            a, b = max(a, lo), min(b, hi)
+        for a, b in self.bucket_ranges(lo, hi, reverse):
             if a < b:
                 handles.append(dist.all_reduce(self.gflat[a:b], op=dist.ReduceOp.SUM, async_op=True))
         if wait:
@@ -442,12 +460,13 @@ class HipTrainer:
             self._allreduce()
         else:
             # phase A is done: every gradient from late_start on is final -> reduce it while phase B (high-resolution layers) runs
-            late = self._allreduce(self.late_start, self.numel, wait=False)
+            # in reverse creation order (decoder, then layer4, then layer3: the order backward finished them), one all-reduce per module-aligned bucket
+            late = self._allreduce(self.late_start, self.numel, wait=False, reverse=True)
             if self._graph_b is not None:
                 self._graph_b.replay()
             else:
                 self._backward_rest()
-            early = self._allreduce(0, self.late_start, wait=False)
+            early = self._allreduce(0, self.late_start, wait=False, reverse=True)
             for h in late + early:
                 h.wait()
         self._optimizer()

@@ -131,11 +131,54 @@ def _worker_cut(rank, world, port, out):
         assert tr._cut is not None and 0 < tr.late_start < tr.numel      # early = `early.*`, late = `layer3.*`
         x, t = _data(8)
         half = slice(rank * 4, rank * 4 + 4)
-        for _ in range(3):
-            tr.step({"x": x[half], "t": t[half]})
+        sent, real = [], dist.all_reduce
+
+        def spy(tensor, *a, **k):                 # the order and extent of every gradient all-reduce of a step
+            sent.append((tensor.data_ptr() - tr.gflat.data_ptr()) // 4)
+            return real(tensor, *a, **k)
+        dist.all_reduce = spy
+        try:
+            for _ in range(3):
+                sent.clear()
+                tr.step({"x": x[half], "t": t[half]})
+        finally:
+            dist.all_reduce = real
+        # late part first, last-created bucket first inside each part (the order backward finalises them), every element exactly once
+        late = [o for o in sent if o >= tr.late_start]
+        early = [o for o in sent if o < tr.late_start]
+        assert sent == late + early and late == sorted(late, reverse=True) and early == sorted(early, reverse=True) and len(late) > 1
+        ranges = tr.bucket_ranges(tr.late_start, tr.numel, reverse=True) + tr.bucket_ranges(0, tr.late_start, reverse=True)
+        assert [a for a, _ in ranges] == sent and sorted(ranges)[0][0] == 0 and sorted(ranges)[-1][1] == tr.numel
+        assert all(b == c for (_, b), (c, _) in zip(sorted(ranges), sorted(ranges)[1:]))
         out[rank] = tr.pflat.clone()
     finally:
         dist.destroy_process_group()
+
+
+def test_gradient_buckets_follow_module_boundaries_in_reverse_order():
+    """The all-reduce buckets of the data-parallel step: module-aligned (decoder | layer4 | layer3 | ...) slices of the flat gradient, at most bucket_mb
+    each, sent last-created first like DDP's reducer (detectron2/utils/setup.py:L38-45)."""
+    import torch.nn as nn
+    from simpledepthestimation_amd.engine.trainer import HipTrainer, ParamGroup
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = nn.ModuleDict({f"layer{i}": nn.Linear(8 * i, 8 * i) for i in range(1, 5)})
+            self.decoder = nn.Sequential(nn.Linear(32, 16), nn.Linear(16, 1))
+    m = Net()
+    groups = [ParamGroup("encoder", m.encoder.named_parameters(prefix="depth_net.encoder"), 1e-3, 0.0),
+              ParamGroup("decoder", m.decoder.named_parameters(prefix="depth_net.decoder"), 1e-3, 0.0)]
+    tr = HipTrainer(m, groups, adam_fn=torch_adam, bucket_mb=200 * 4 / (1 << 20))          # 200-element buckets
+    offs = {n: tr._off[id(p)] for g in tr.groups for n, p in g.named_params}
+    starts = [offs[f"depth_net.encoder.layer{i}.weight"] for i in range(1, 5)] + [offs["depth_net.decoder.0.weight"]]
+    fwd = tr.bucket_ranges()
+    assert fwd[0][0] == 0 and fwd[-1][1] == tr.numel and all(b == c for (_, b), (c, _) in zip(fwd, fwd[1:]))
+    assert all(b - a <= 200 for a, b in fwd) and set(starts) <= {a for a, _ in fwd}           # every module starts a bucket
+    assert tr.bucket_ranges(reverse=True) == fwd[::-1]
+    l3 = offs["depth_net.encoder.layer3.weight"]
+    late = tr.bucket_ranges(l3, tr.numel, reverse=True)
+    assert late[0][1] == tr.numel and late[-1][0] == l3 and late[0][0] >= offs["depth_net.decoder.0.weight"]      # decoder buckets go first
 
 
 def test_dp2_two_phase_backward_matches_single_process():
