@@ -172,6 +172,10 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_kernel(const T* __restrict__
     store_vec<T>(dx + it.pix * (long)D + it.c0, acc);
 }
 
+// (Tried in round 3 and removed: an LDS-tiled data gradient -- 4 x 8 pixels x 64 channels per workgroup, the dy halo staged once, weights in LDS, the
+// chunk-edge channels as a correction pass.  Bit-for-bit the same results, but 1.74 ms against 1.55 ms for the kernel above at 12 x 96 x 320 x 256: the
+// kernel is bound by its conversion / shuffle instruction mix, not by the 27-fold re-reads, which L1 / L2 absorb.  profiles/README.md, round 3.)
+
 // part[block][f*28 + t] (t < 27: weight tap, t == 27: bias) = this workgroup's share of
 //   dw[f][kd][kh][kw] = sum dy[b,h,w,f*D+ch] * x[b,h+kh-1,w+kw-1,ch+kd-1] ;  dbias[f] = sum dy[b,h,w,f*D+ch]
 constexpr int WG_ITEMS = 8;      // (pixel, channel group) items per thread at most; small layers take fewer so that the grid still fills the CUs

@@ -334,7 +334,8 @@ def test_group_norm_elu(NN, dtype, C, H, W):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,D,H,W", [(2, 16, 5, 7), (1, 64, 9, 12), (2, 256, 3, 4)])
+@pytest.mark.parametrize("B,D,H,W", [(2, 16, 5, 7), (1, 64, 9, 12), (2, 256, 3, 4),
+                                     (2, 64, 40, 36), (1, 192, 47, 50), (3, 128, 26, 33)])     # more than 64 channel groups per wave boundary / several waves per pixel row
 def test_conv3d_pack(NN, dtype, B, D, H, W):
     """layers01.py:L223-298: x.unsqueeze(1) -> Conv3d(1, 8, 3, padding=1) -> view(b, 8*D, h, w), forward and all three gradients."""
     g = torch.Generator().manual_seed(D + H)
