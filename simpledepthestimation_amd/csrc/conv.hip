@@ -1430,9 +1430,9 @@ int fill_gather(const sde_conv_desc* d, Gather& g, const char* who) {
 namespace sdeconv {
 bool pgemm_applicable(const Gather& g, int dtype, int ldy);
 bool pgemm_bnbwd_ok(const Gather& g, int dtype, int ldy, int Cout, int depth);
-int pgemm_tile(long M, int ldy);
+int pgemm_tile(const Gather& g, int ldy);
 int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s);
-int pgemm_stats_rows(const Gather& g, int ldy, int depth);
+int pgemm_stats_rows(const Gather& g, int ldy, int depth, bool bnbwd = false);
 // narrow-input 3x3 layers at high resolution (conv_halo_small.hip)
 bool chalo_applicable(const Gather& g, int dtype, int ldy);
 int chalo_run(const IGemmP& p, int dtype, hipStream_t s);
@@ -1466,7 +1466,7 @@ extern "C" {
 static int pick_ksplit(const Gather& g, int dtype, int ldy) {
     const bool pg = use_pgemm(g, dtype, ldy);
     if (!g_splitk || ldy % 4) return 1;
-    if (pg ? (pgemm_tile(g.M, ldy) != 64064 || g.mode == SDE_SRC_ZEROINS) : (use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064)) return 1;
+    if (pg ? (pgemm_tile(g, ldy) != 64064 || g.mode == SDE_SRC_ZEROINS) : (use_halo(g, dtype, ldy) || pick_tile(g.M, ldy, g.Ktot) != 64064)) return 1;
     const long tiles = (long)sde_cdiv(g.M, 64) * sde_cdiv(ldy, 64);
     const int nk = sde_cdiv(g.Ktot, SDE_IS16(dtype) ? 64 : 32);
     // register-staged kernel (4 workgroups per CU, pipeline drained per tile): split below 384 tiles towards 768 workgroups (measured 10.12 ->
@@ -1562,7 +1562,7 @@ int sde_conv_dgrad_bnbwd_rows(const sde_conv_desc* d, int Cout, int ldy) {
     Gather g;
     if (!d || fill_gather(d, g, "sde_conv_dgrad_bnbwd_rows") != SDE_OK) return 0;
     const int kind = bnbwd_kind(g, d->dtype, ldy, Cout);
-    if (kind == 1) return sdeconv::pgemm_stats_rows(g, ldy, g_pgemm_depth);
+    if (kind == 1) return sdeconv::pgemm_stats_rows(g, ldy, g_pgemm_depth, true);
     if (kind == 2) return halo_tiles_m(g);
     return 0;
 }
@@ -1588,7 +1588,7 @@ int sde_conv_dgrad_bnbwd(const sde_conv_desc* d, const void* w_packed, void* gm,
 int sde_conv_fwd_variant(const sde_conv_desc* d, int ldy) {
     Gather g;
     if (gather_of(d, g) == SDE_OK && use_chalo(g, d->dtype, ldy)) return 5000000 + g.Cin * 1000 + ldy;            // 5<Cin><ldy>: narrow-input halo kernel (without BN statistics)
-    if (gather_of(d, g) == SDE_OK && use_pgemm(g, d->dtype, ldy)) return 7000000 + pgemm_tile(g.M, ldy);   // 7<BM><BN>: persistent LDS-DMA GEMM
+    if (gather_of(d, g) == SDE_OK && use_pgemm(g, d->dtype, ldy)) return 7000000 + pgemm_tile(g, ldy);   // 7<BM><BN>: persistent LDS-DMA GEMM
     if (gather_of(d, g) == SDE_OK && use_halo(g, d->dtype, ldy)) return 3128000 + halo_bn(g, ldy);      // 3128<BN>: LDS-halo 3x3 kernel
     return pick_tile((long)d->Bn * d->OH * d->OW, ldy, d->KH * d->KW * (d->C0 + d->C1));
 }

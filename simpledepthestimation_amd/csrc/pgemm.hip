@@ -164,12 +164,18 @@ __device__ __forceinline__ void pg_lds_store4(unsigned addr, unsigned a) { asm v
 
 // BNB: BatchNorm-backward epilogue (IGemmP::bn_y / bnp): the output tile is masked with relu'(bn(y_bn)) and the statistics slab receives
 // (sum gm, sum gm * xhat) instead of (sum y, sum y^2).
-template <typename T16, int BM, int BN, int SRC, int D, bool BNB = false>
-__global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
+// NW waves per workgroup as WGM x (NW / WGM): 4 = 2 x 2 (64x64 tiles, three workgroups per CU); 8 = 4 x 2 / 2 x 4 for the 128x64 / 128x128 tiles of the
+// long-K layers, where a 64x64 tile moves 1 KB of L2 -> LDS traffic per MFMA and 128x128 half of that (round 3; the round-2 128-wide tiles kept 4 waves,
+// 236 VGPRs and one workgroup per CU, and lost).
+template <typename T16, int BM, int BN, int SRC, int D, bool BNB = false, int NW = 4, int WGM = 2>
+__global__ void __launch_bounds__(64 * NW) pgemm_kernel(const PGemmP q) {
     typedef typename PgType<T16>::frag frag_t;
-    constexpr int WTM = BM / 2, WTN = BN / 2;          // 2 x 2 waves
+    constexpr int PG_THREADS = 64 * NW;                // (shadows the namespace constant: every loop below strides by the workgroup's own size)
+    constexpr int WGN = NW / WGM;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;      // WGM x WGN waves
     constexpr int FM = WTM / 32, FN = WTN / 32;        // 32x32 fragments per wave: pixels (MFMA columns) x channels (MFMA rows)
-    constexpr int XP = BM / 32, WP = BN / 32;          // DMA pieces (8 rows x 128 B) per wave per stage
+    constexpr int XP = BM / (8 * NW), WP = BN / (8 * NW);   // DMA pieces (8 rows x 128 B) per wave per stage
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile / wave grid");
     constexpr int L = XP + WP;                         // DMA instructions per wave per stage
     constexpr int STAGE_BYTES = (BM + BN) * PG_STAGE_K_BYTES;
     constexpr int BIAS_BYTES = BN * 4;
@@ -178,7 +184,8 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     constexpr int EN = BN > 64 ? 64 : BN, NCH = BN / EN;   // the epilogue stages EN output channels at a time
     constexpr int CST = EN * 2 + 16;                   // staging-tile row stride (bytes): 16-byte aligned, conflict-free 8-byte column writes
     // staging tile + the per-tile BatchNorm reduction scratch red[PARTS][EN][2] floats behind it
-    static_assert(BM * CST + (PG_THREADS / (EN / 2)) * EN * 8 <= STAGE_BYTES, "the output staging tile and the statistics scratch must fit into one ring slot");
+    constexpr int ST = PG_THREADS > 256 ? 256 : PG_THREADS;      // threads of the statistics passes (the scratch behind the staging tile holds ST / 32 row sets)
+    static_assert(BM * CST + (ST / (EN / 2)) * EN * 8 <= STAGE_BYTES, "the output staging tile and the statistics scratch must fit into one ring slot");
     static_assert(D >= 3 && (D - 2) * L <= 60, "ring depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [D][X: BM rows | W: BN rows], [D][BN] bias
 
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     const Gather& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, lh = lane >> 5;
     const int grid = gridDim.x;
 
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             l_a = k.a; l_b = k.b; l_nta = k.nta; l_ntb = k.ntb;
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
-                const int row = wave * (BM / 4) + i * 8 + drow;
+                const int row = wave * (BM / NW) + i * 8 + drow;
                 const int chunk = dslot ^ ((row >> 1) & 7);
                 const int m = m0 + row;
                 const bool ok = m < k.M;
@@ -232,7 +239,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             }
 #pragma unroll
             for (int i = 0; i < WP; ++i) {
-                const int row = wave * (BN / 4) + i * 8 + drow;
+                const int row = wave * (BN / NW) + i * 8 + drow;
                 const int chunk = dslot ^ ((row >> 1) & 7);
                 const int n = n0 + row;
                 woff[i] = n < p.ldy ? (unsigned)(n * g.Ktot * 2 + chunk * 16) : kOOB;
@@ -243,7 +250,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
         if (SRC == SRC_1X1 && g.stride == 1) {       // output pixel m IS input pixel m: no coordinates needed
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
-                const int row = wave * (BM / 4) + i * 8 + drow;
+                const int row = wave * (BM / NW) + i * 8 + drow;
                 const int chunk = dslot ^ ((row >> 1) & 7);
                 const int m = m0 + row;
                 xnb[i] = 0; xih[i] = 0; xiw[i] = 0;
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
         } else
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const int row = wave * (BM / 4) + i * 8 + drow;
+            const int row = wave * (BM / NW) + i * 8 + drow;
             const int chunk = dslot ^ ((row >> 1) & 7);
             const int m = m0 + row;
             const bool ok = m < g.M;
@@ -270,7 +277,7 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
         if (!(q.fast && l_item > 0)) {           // fast decode: tile_n never changes
 #pragma unroll
             for (int i = 0; i < WP; ++i) {
-                const int row = wave * (BN / 4) + i * 8 + drow;
+                const int row = wave * (BN / NW) + i * 8 + drow;
                 const int chunk = dslot ^ ((row >> 1) & 7);
                 const int n = n0 + row;
                 woff[i] = n < p.ldy ? (unsigned)(n * g.Ktot * 2 + chunk * 16) : kOOB;
@@ -293,8 +300,8 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     auto issue_next = [&]() {
         if (lwk.nk == 0) return;         // no work left: nothing to issue (uniform)
         unsigned char* slot = smem + (issued % D) * SLOT_BYTES;
-        unsigned char* sX = slot + (wave * (BM / 4)) * PG_STAGE_K_BYTES;
-        unsigned char* sW = slot + BM * PG_STAGE_K_BYTES + (wave * (BN / 4)) * PG_STAGE_K_BYTES;
+        unsigned char* sX = slot + (wave * (BM / NW)) * PG_STAGE_K_BYTES;
+        unsigned char* sW = slot + BM * PG_STAGE_K_BYTES + (wave * (BN / NW)) * PG_STAGE_K_BYTES;
         const unsigned soff = SRC == SRC_ZEROINS_ZERO
                                   ? (unsigned)((((l_a + 2 * l_kh) * g.KW + l_b + 2 * l_kw) * g.C0 + l_cb) * 2)      // K position of tap (a + 2 ta, b + 2 tb), channel block cb
                                   : (unsigned)(lwk.s_begin + ls) * (unsigned)PG_STAGE_K_BYTES;
@@ -574,19 +581,21 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
             if (p.stats) {
                 // per-tile column sums of y and y^2 (of the rounded values) over the valid rows: PARTS interleaved row sets per column
                 // thread = (channel pair tid % (EN/2), row set tid / (EN/2)): one 4-byte LDS read per row, packed fp32 math
-                constexpr int PARTS = PG_THREADS / (EN / 2);
+                constexpr int PARTS = ST / (EN / 2);
                 float* red = reinterpret_cast<float*>(sC + BM * CST);       // [PARTS][EN][2]
                 const int c2 = tid % (EN / 2), part = tid / (EN / 2);
                 const int rows = (g.M - m0) < BM ? (g.M - m0) : BM;
                 pg_f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+                if (PG_THREADS == ST || tid < ST) {
 #pragma unroll 4
-                for (int r = part; r < rows; r += PARTS) {
-                    const pg_f32x2 t = PgType<T16>::unpack2(*reinterpret_cast<const unsigned*>(sC + r * CST + c2 * 4));
-                    s1 += t; s2 += t * t;
+                    for (int r = part; r < rows; r += PARTS) {
+                        const pg_f32x2 t = PgType<T16>::unpack2(*reinterpret_cast<const unsigned*>(sC + r * CST + c2 * 4));
+                        s1 += t; s2 += t * t;
+                    }
                 }
                 if (q.stats_acc) { st1[ch] += s1; st2[ch] += s2; st_n0 = n0; continue; }
                 // (one 16-byte store: two 8-byte asm stores fed from the halves of the packed sums were given the SAME register pair by hipcc)
-                pg_lds_store16(sC_a + BM * CST + (part * EN + 2 * c2) * 8, s1[0], s2[0], s1[1], s2[1]);
+                if (PG_THREADS == ST || tid < ST) pg_lds_store16(sC_a + BM * CST + (part * EN + 2 * c2) * 8, s1[0], s2[0], s1[1], s2[1]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (tid < EN && nc0 + tid < p.Cout) {
@@ -603,13 +612,13 @@ __global__ void __launch_bounds__(PG_THREADS) pgemm_kernel(const PGemmP q) {
     }
     pg_wait_vmcnt<0>();      // nothing may be in flight into LDS when the workgroup ends
     if (p.stats && q.stats_acc) {
-        constexpr int PARTS = PG_THREADS / (EN / 2);
+        constexpr int PARTS = ST / (EN / 2);
         float* red = reinterpret_cast<float*>(smem);                       // [NCH][PARTS][EN][2]
         __builtin_amdgcn_s_barrier();                                      // every wave is done with the ring
         const int c2 = tid % (EN / 2), part = tid / (EN / 2);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            pg_lds_store16(pg_lds_addr(smem) + (((ch * PARTS + part) * EN) + 2 * c2) * 8, st1[ch][0], st2[ch][0], st1[ch][1], st2[ch][1]);
+            if (PG_THREADS == ST || tid < ST) pg_lds_store16(pg_lds_addr(smem) + (((ch * PARTS + part) * EN) + 2 * c2) * 8, st1[ch][0], st2[ch][0], st1[ch][1], st2[ch][1]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -644,12 +653,12 @@ static bool pg_stats_acc(int tiles_n, int tiles_mn, int ksplit, int src, int BM,
     return ksplit == 1 && src != SRC_ZEROINS_ZERO && tiles_mn > grid && (grid >> 3) % tiles_n == 0;
 }
 
-template <typename T16, int BM, int BN, int SRC, int D, bool BNB = false>
+template <typename T16, int BM, int BN, int SRC, int D, bool BNB = false, int NW = 4, int WGM = 2>
 static int pg_launch(const PGemmP& q, hipStream_t s) {
     constexpr int lds = D * ((BM + BN) * PG_STAGE_K_BYTES + BN * 4);      // stage ring + bias ring
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm_kernel<T16, BM, BN, SRC, D, BNB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pgemm_kernel<T16, BM, BN, SRC, D, BNB, NW, WGM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
     int grid = pg_grid_max(BM, BN, D);
@@ -657,18 +666,18 @@ static int pg_launch(const PGemmP& q, hipStream_t s) {
     PGemmP qq = q;
     qq.fast = (q.p.ksplit == 1 && SRC != SRC_ZEROINS_ZERO && grid % 8 == 0 && (grid >> 3) % q.tiles_n == 0) ? 1 : 0;
     qq.tm_step = qq.fast ? (grid >> 3) / q.tiles_n : 0;
-    hipLaunchKernelGGL((pgemm_kernel<T16, BM, BN, SRC, D, BNB>), dim3(grid), dim3(PG_THREADS), lds, s, qq);
+    hipLaunchKernelGGL((pgemm_kernel<T16, BM, BN, SRC, D, BNB, NW, WGM>), dim3(grid), dim3(64 * NW), lds, s, qq);
     return 0;
 }
 
-template <typename T16, int BM, int BN, int D>
+template <typename T16, int BM, int BN, int D, int NW = 4, int WGM = 2>
 static int pg_dispatch_src(const PGemmP& q, int src, hipStream_t s) {
     switch (src) {
-        case SRC_1X1: return pg_launch<T16, BM, BN, SRC_1X1, D>(q, s);
-        case SRC_PLAIN_ZERO: return pg_launch<T16, BM, BN, SRC_PLAIN_ZERO, D>(q, s);
-        case SRC_PLAIN_REFLECT: return pg_launch<T16, BM, BN, SRC_PLAIN_REFLECT, D>(q, s);
-        case SRC_ZEROINS_ZERO: return pg_launch<T16, BM, BN, SRC_ZEROINS_ZERO, D>(q, s);
-        default: return pg_launch<T16, BM, BN, SRC_UPCAT_REFLECT, D>(q, s);
+        case SRC_1X1: return pg_launch<T16, BM, BN, SRC_1X1, D, false, NW, WGM>(q, s);
+        case SRC_PLAIN_ZERO: return pg_launch<T16, BM, BN, SRC_PLAIN_ZERO, D, false, NW, WGM>(q, s);
+        case SRC_PLAIN_REFLECT: return pg_launch<T16, BM, BN, SRC_PLAIN_REFLECT, D, false, NW, WGM>(q, s);
+        case SRC_ZEROINS_ZERO: return pg_launch<T16, BM, BN, SRC_ZEROINS_ZERO, D, false, NW, WGM>(q, s);
+        default: return pg_launch<T16, BM, BN, SRC_UPCAT_REFLECT, D, false, NW, WGM>(q, s);
     }
 }
 
@@ -692,22 +701,26 @@ int pgemm_src_kind(const Gather& g) {
     return g.reflect ? SRC_PLAIN_REFLECT : SRC_PLAIN_ZERO;
 }
 
-// Tile choice (one place): BM*1000 + BN.  Measured on every layer shape of the ResNet-50 / ResNet-18 workloads (profiles/r02_gemm_microbench.txt):
-// 64x64 with a 3-stage ring (3 workgroups per CU) is the fastest or within 3 % of it everywhere; 128x64 (2 per CU) loses 5-40 %, 128x128
-// (4 waves, 236 VGPRs, one workgroup per CU) runs 1.5-2x slower -- at this network's sizes the tiles are bound by how many loads a CU keeps
-// in flight, not by operand reuse.  The larger instantiations stay reachable through SDE_OPT_PGEMM_TILE for measurements.
+// Tile choice (one place): BM*1000 + BN.  64x64 with a 3-stage ring (four waves, three workgroups per CU) everywhere.  Round 3 built eight-wave
+// workgroups for the 128-row tiles (128x64: 4 x 2 waves, two workgroups per CU; 128x128: 2 x 4 waves, one per CU) -- the round-2 forms kept four waves,
+// 236 VGPRs, and lost 5-40 %.  Stand-alone (profiles/r03l_gemm_microbench.txt, every forward / data-gradient shape of the ResNet-50 workload) 128x64 is
+// 3-10 % faster wherever a launch has >= 640 of those tiles (layer1, the expanding 1x1 layers of layer2 / layer3, the decoder's full-correlation data
+// gradients) and 5-10 % slower at 360 tiles (tail of the last wave of tiles), 128x128 wins on three shapes.  Inside the step a rule "128x64 from 640
+// tiles" measured 6.55-6.58 against 6.58-6.60 ms (Supervised-R50), 4.34 against 4.27 (MonoDepth2-R18), 7.70 against 7.67 (MonoDepth2-R50): next to the
+// weight-gradient queue the bigger workgroups lose what they win alone, so the rule is NOT applied; the instantiations stay reachable through
+// SDE_OPT_PGEMM_TILE (tests/test_gpu_pgemm.py covers them).
 int g_pgemm_force_tile = 0;     // sde_conv_set_option(SDE_OPT_PGEMM_TILE, 64064 | 128064 | 128128 | 0 = automatic)
-int pgemm_tile(long M, int ldy) {
-    (void)M; (void)ldy;
+int pgemm_tile(const Gather& g, int ldy) {
+    (void)g; (void)ldy;
     return g_pgemm_force_tile ? g_pgemm_force_tile : 64064;
 }
 
-static int pg_depth(int tile, int depth) { return tile == 128128 || depth == 3 ? 3 : 4; }      // the ring depth pgemm_run_t instantiates
+static int pg_depth(int tile, int depth) { return tile != 64064 || depth == 3 ? 3 : 4; }      // the ring depth pgemm_run_t instantiates
 
 // The layers whose BatchNorm-backward reduction can ride in this kernel's epilogue: 64x64 tiles, ring depth 3, one K range, 1x1 or zero-padded
 // k x k stride-1 sources, full 64-channel output tiles.
 bool pgemm_bnbwd_ok(const Gather& g, int dtype, int ldy, int Cout, int depth) {
-    if (!pgemm_applicable(g, dtype, ldy) || pgemm_tile(g.M, ldy) != 64064 || depth != 3) return false;
+    if (!pgemm_applicable(g, dtype, ldy) || depth != 3 || (g_pgemm_force_tile && g_pgemm_force_tile != 64064)) return false;      // (the fused epilogue exists for 64x64 tiles: pgemm_run takes them for such a launch whatever pgemm_tile says)
     const int src = pgemm_src_kind(g);
     return (src == SRC_1X1 || src == SRC_PLAIN_ZERO) && g.stride == 1 && Cout % 64 == 0 && ldy == Cout;
 }
@@ -715,15 +728,15 @@ bool pgemm_bnbwd_ok(const Gather& g, int dtype, int ldy, int Cout, int depth) {
 template <typename T16>
 static int pgemm_run_t(const PGemmP& q, int tile, int src, int depth, hipStream_t s) {
     if (q.p.bn_y) return src == SRC_1X1 ? pg_launch<T16, 64, 64, SRC_1X1, 3, true>(q, s) : pg_launch<T16, 64, 64, SRC_PLAIN_ZERO, 3, true>(q, s);
-    if (tile == 128128) return pg_dispatch_src<T16, 128, 128, 3>(q, src, s);
-    if (tile == 128064) return depth == 3 ? pg_dispatch_src<T16, 128, 64, 3>(q, src, s) : pg_dispatch_src<T16, 128, 64, 4>(q, src, s);
+    if (tile == 128128) return pg_dispatch_src<T16, 128, 128, 3, 8, 2>(q, src, s);      // eight waves, 2 x 4: one workgroup per CU
+    if (tile == 128064) return pg_dispatch_src<T16, 128, 64, 3, 8, 4>(q, src, s);       // eight waves, 4 x 2: two workgroups per CU
     return depth == 3 ? pg_dispatch_src<T16, 64, 64, 3>(q, src, s) : pg_dispatch_src<T16, 64, 64, 4>(q, src, s);
 }
 
 int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s) {
     PGemmP q;
     q.p = p;
-    const int tile = pgemm_tile(p.g.M, p.ldy);
+    const int tile = p.bn_y ? 64064 : pgemm_tile(p.g, p.ldy);
     const int BM = tile / 1000, BN = tile % 1000;
     q.tiles_n = sde_cdiv(p.ldy, BN);
     q.tiles_mn = sde_cdiv(p.g.M, BM) * q.tiles_n;
@@ -749,8 +762,8 @@ int pgemm_run(const IGemmP& p, int dtype, int depth, hipStream_t s) {
 }
 
 // Rows of the BatchNorm-statistics slab pgemm_run writes for this layer (split-K layers: the finish kernel's, one per 64 rows).
-int pgemm_stats_rows(const Gather& g, int ldy, int depth) {
-    const int tile = pgemm_tile(g.M, ldy);
+int pgemm_stats_rows(const Gather& g, int ldy, int depth, bool bnbwd) {
+    const int tile = bnbwd ? 64064 : pgemm_tile(g, ldy);
     const int BM = tile / 1000, BN = tile % 1000;
     depth = pg_depth(tile, depth);
     const int tiles_n = sde_cdiv(ldy, BN), tiles_mn = sde_cdiv(g.M, BM) * tiles_n;

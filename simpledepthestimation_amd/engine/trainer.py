@@ -106,7 +106,7 @@ class HipTrainer:
             for n_, p in g.named_params:
                 parts = n_.split(".")
                 i_layer = next((i for i, t in enumerate(parts) if t.startswith("layer") or t in ("decoder", "pose_net", "conv1", "bn1")), None)
-                mod = (g.name, ".".join(parts[:i_layer + 1]) if i_layer is not None else parts[0])
+                mod = (g.name, ".".join(parts[:i_layer] + ["stem" if parts[i_layer] in ("conv1", "bn1") else parts[i_layer]]) if i_layer is not None else parts[0])
                 if mod != prev_mod:
                     self._module_cuts.add(off)
                     prev_mod = mod
