@@ -424,11 +424,13 @@ class HipTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph, graph_b = torch.cuda.CUDAGraph(), None
-        with torch.cuda.graph(graph):
+        # thread-local capture mode: other threads of the process keep making HIP calls while the step is captured -- RCCL's watchdog thread once the
+        # process group exists (N > 1), a data loader's pin-memory thread -- and in the default "global" mode any of them invalidates the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             static_out = self._fwd_bwd(dict(self._static_batch))
         if self._cut is not None:                  # phase B: the rest of backward, same memory pool, replayed after phase A
             graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_b, pool=graph.pool()):
+            with torch.cuda.graph(graph_b, pool=graph.pool(), capture_error_mode="thread_local"):
                 self._backward_rest()
         with torch.no_grad():
             for b, k in zip(self.model.buffers(), kept_buffers):
