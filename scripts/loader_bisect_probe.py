@@ -99,17 +99,24 @@ run("resident, nothing beside the step", None)
 from simpledepthestimation_amd.data import DevicePrefetcher  # noqa: E402
 
 
-def run_pf(name, use_hb, threaded=True, n=60):
+def run_pf(name, mode, slots=3, n=60):
+    """mode: 'fixed' = the prefetcher runs beside steps on a fixed resident batch; 'copy' = aug on the copy stream, step consumes the batch (D2D copies into the
+    static inputs); 'inplace' = uploads only, HipTrainer.input_transform writes the static inputs"""
     gen, _ = bench.host_loader("SupDepthModel", 12, 192, 640, 1, n)
-    pf = DevicePrefetcher(gen, dev, device_aug=aug)
+    trainer.input_transform = aug if mode == "inplace" else None
+    pf = DevicePrefetcher(gen, dev, device_aug=(None if mode == "inplace" else aug), slots=slots)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for hb_ in pf:
-        trainer.step(hb_ if use_hb else batch)
+        trainer.step(batch if mode == "fixed" else hb_)
     torch.cuda.synchronize()
+    trainer.input_transform = None
     print(f"{name:58s} {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step")
 
 
-run_pf("DevicePrefetcher, step consumes a FIXED batch", False)
-run_pf("DevicePrefetcher, step consumes the prefetched batch", True)
-run("resident, nothing beside the step", None)
+for rep in range(3):
+    run_pf("prefetcher beside steps on a FIXED batch", "fixed")
+    run_pf("prefetcher, aug on copy stream, step consumes batch", "copy")
+    run_pf("prefetcher uploads, transform in place (bench form)", "inplace")
+    run_pf("  ... the same with 4 slots", "inplace", slots=4)
+    run("resident, nothing beside the step", None)
