@@ -136,13 +136,16 @@ def roofline_pass(trainer, batch, steps, dtype, workload="sup_r50", step_ms=None
         if kind.startswith("photo"):
             f = photo.setdefault((kind, meta["h"], meta["w"]), {"ms": 0.0, "bytes": 0.0, "launches": 0})
             f["ms"] += ms; f["bytes"] += nbytes; f["launches"] += 1
+    all_recs = recs
     recs = [r for r in recs if not r[0].startswith("photo")]
     hbm = None
     if photo:
         k0 = max((k for k in photo if k[0] == "photo_fwd"), key=lambda k: k[1] * k[2])        # the full-resolution scale
         v = photo[k0]
         gbps = v["bytes"] / (v["ms"] * 1e-3) / 1e9
-        hbm = {"bound": "hbm", "kernel": f"photo_fwd_kernel (warp + SSIM + L1 + min/automask), scale {k0[1]}x{k0[2]}", "achieved": round(gbps, 1),
+        nsc = next((m.get("scales") for k_, _w, _v, _ms, _med, m in [(r[0], r[1], r[2], r[3], r[4], r[5]) for r in all_recs] if k_ == "photo_fwd" and m), None)
+        where = f"all {nsc} scales from {k0[1]}x{k0[2]} down in one launch" if nsc else f"scale {k0[1]}x{k0[2]}"
+        hbm = {"bound": "hbm", "kernel": f"photo_fwd_kernel (warp + SSIM + L1 + min/automask), {where}", "achieved": round(gbps, 1),
                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None,
                "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                "all": {f"{k[0]}:{k[1]}x{k[2]}": {"us": round(x["ms"] * 1e3 / x["launches"], 2), "GBps": round(x["bytes"] / (x["ms"] * 1e-3) / 1e9, 1)}
@@ -413,6 +416,9 @@ def main():
                 L.lib().sde_bn_set_fuse(int(v))
             elif k == "bnbwd":                  # --opt bnbwd=0 -> BatchNorm's backward reduce as its own pass everywhere (A/B)
                 HN.BNBWD_FUSED = bool(int(v))
+            elif k == "photo_multi":            # --opt photo_multi=0 -> one photometric launch per scale (A/B)
+                from simpledepthestimation_amd.modeling.meta_arch import MonoDepth2 as MD
+                MD.MULTI_SCALE_PHOTO = bool(int(v))
             elif k == "head_bias":              # --opt head_bias=0 -> disparity-head bias gradients by the separate pass
                 HN.HEAD_BIAS_FUSED = bool(int(v))
             else:

@@ -89,6 +89,15 @@ int sde_photo_fwd(const sde_photo_desc* d, float* const* sampled, uint8_t* sel, 
  * d_depth [B,1,h,w]; pose_partial [sde_photo_num_blocks(...,1) * nctx * 12] workspace; d_pose[j] [B,4,4]. */
 int sde_photo_bwd(const sde_photo_desc* d, const float* const* sampled, const uint8_t* sel, const float* gout, float gscale, float* d_depth,
                   int accumulate_depth, float* pose_partial, float* const* d_pose, int accumulate_pose, sde_stream_t stream);
+/* Every scale of the loss (MonoDepth2.py:L78-112 loops over the four decoder scales) in ONE launch per phase: d [n] descriptors (n <= 4, same batch and
+ * contexts, no clip thresholds), fine scale first; sampled [n][SDE_MAX_CTX], sel [n], partial [n] (sizes as for the single-scale calls);
+ * loss_out [n] = mean over pixels of each scale's reduced map -- bit-identical to n calls of sde_photo_fwd.  Backward: gout [n] device scalars (the
+ * upstream gradient of each scale's loss), d_depth [n], pose_partial [n]; d_pose [SDE_MAX_CTX] receives the SUM over the scales (written, not
+ * accumulated).  The coarse scales (1/4 ... 1/64 of the pixels) are launch-sized on their own; behind the fine scale's workgroups they fill its tail. */
+int sde_photo_multi_fwd(const sde_photo_desc* d, int n, float* const* sampled, uint8_t* const* sel, float* const* partial, float* loss_out,
+                        sde_stream_t stream);
+int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* sampled, const uint8_t* const* sel, const float* gout, float* const* d_depth,
+                        float* const* pose_partial, float* const* d_pose, sde_stream_t stream);
 
 /* Stand-alone SSIM distance map, the callable module of detectron2/modeling/losses/ssim_loss.py:L6-53:
  * out[b,c,h,w] = clamp((1 - SSIM(x, y)) / 2, 0, 1) with ReflectionPad2d(1) + 3x3 mean; x, y, out planar [B,C,H,W] fp32 (the training path

@@ -233,18 +233,20 @@ __device__ __forceinline__ float ssim_from_moments(float sx, float sy, float sxx
     return fminf(fmaxf((1.0f - n * __builtin_amdgcn_rcpf(d)) * 0.5f, 0.f), 1.f);     // v_rcp_f32 (1 ulp) instead of the 10-instruction IEEE division
 }
 
+// bx, by, bz / gdx, gdy: this workgroup's tile coordinates and the tile grid of ITS scale (the multi-scale launch packs the grids of all scales
+// into one linear grid; the single-scale launch passes blockIdx / gridDim)
 template <int NCTX>
-__global__ void __launch_bounds__(FT_N) photo_fwd_kernel(PhotoArgs a) {
+__device__ __forceinline__ void photo_fwd_body(const PhotoArgs& a, const int bx, const int by, const int bz, const int gdx, const int gdy) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sA = lds;                        // [3][FT_N]
     float* sC = sA + 3 * FT_N;              // [NCTX][3][FT_N]  raw context frames (identity / auto-mask maps)
     float* sS = sC + NCTX * 3 * FT_N;       // [NCTX][3][FT_N]  warped samples
     float* red = sS + NCTX * 3 * FT_N;      // [16]
     const int tx = threadIdx.x, ty = threadIdx.y, lp = ty * FT_W + tx;
-    const int b = blockIdx.z, h = a.h, w = a.w;
+    const int b = bz, h = a.h, w = a.w;
     const long hw = (long)h * w;
     // position in the image of this thread (with halo); reflected when outside (ReflectionPad2d(1))
-    const int gx = blockIdx.x * (FT_W - 2) + tx - 1, gy = blockIdx.y * (FT_H - 2) + ty - 1;
+    const int gx = bx * (FT_W - 2) + tx - 1, gy = by * (FT_H - 2) + ty - 1;
     const int rx = reflect_idx(gx, w), ry = reflect_idx(gy, h);
     const bool usable = rx >= 0 && rx < w && ry >= 0 && ry < h;   // false only far outside on ragged tiles
     const bool inimg = gx >= 0 && gx < w && gy >= 0 && gy < h;
@@ -341,7 +343,31 @@ __global__ void __launch_bounds__(FT_N) photo_fwd_kernel(PhotoArgs a) {
         if (a.sel) a.sel[b * hw + (long)gy * w + gx] = a.reduce_mean ? (a.thr ? (uint8_t)clipped : 255) : (((clipped >> bi) & 1u) ? 254 : (uint8_t)bi);
     }
     const float s = sde_block_sum(v, red);
-    if (lp == 0) a.partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+    if (lp == 0) a.partial[(bz * gdy + by) * gdx + bx] = s;
+}
+
+template <int NCTX>
+__global__ void __launch_bounds__(FT_N) photo_fwd_kernel(PhotoArgs a) {
+    photo_fwd_body<NCTX>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// All scales of the loss in ONE launch: the coarse scales are launch-sized on their own (31 / 19 / 14 us for 1/4 ... 1/64 of the pixels of the
+// 90 us full-resolution launch); packed behind the fine scale's workgroups they fill its tail instead.  Scale s owns the linear blocks
+// [first[s], first[s+1]); fine scale first, so the long workgroups start first.
+constexpr int PH_MAX_SCALES = 4;
+struct PhotoMulti {
+    PhotoArgs a[PH_MAX_SCALES];
+    int first[PH_MAX_SCALES + 1];
+    int gdx[PH_MAX_SCALES], gdy[PH_MAX_SCALES];
+    int n;
+};
+
+template <int NCTX>
+__global__ void __launch_bounds__(FT_N) photo_fwd_multi_kernel(const PhotoMulti m) {
+    int s = 0;
+    while (s + 1 < m.n && (int)blockIdx.x >= m.first[s + 1]) ++s;
+    const int local = blockIdx.x - m.first[s], gdx = m.gdx[s], gdy = m.gdy[s];
+    photo_fwd_body<NCTX>(m.a[s], local % gdx, (local / gdx) % gdy, local / (gdx * gdy), gdx, gdy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,17 +391,17 @@ struct PhotoBwdArgs {
 // DENSE: the instantiation for grids that fill the GPU several times over (the two fine scales): compiled for six waves per SIMD (80 VGPRs, three
 // workgroups per CU; seven values spill) -- 164 -> 145 us at 192x640, 55 -> 50 at 96x320; the coarse scales, whose grids do not fill the CUs, keep
 // the spill-free 92-VGPR form (they lose 15 % with the spills: 22.7 -> 26.1, 17.5 -> 20.2 us)
-template <int NCTX, bool DENSE = false>
-__global__ void __launch_bounds__(BT_N, DENSE ? 6 : 1) photo_bwd_kernel(PhotoBwdArgs a) {
+template <int NCTX>
+__device__ __forceinline__ void photo_bwd_body(const PhotoBwdArgs& a, const int bx, const int by, const int bz, const int gdx, const int gdy) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sA = lds;                  // [3][BT_N]
     float* sX = sA + 3 * BT_N;        // [3][BT_N]     current context's warped sample
     float* sK = sX + 3 * BT_N;        // [3][3][BT_N]  per-window coefficients (dA, dB, dC) per channel
     float* red = sK + 9 * BT_N;       // [waves][NCTX][12]
     const int tx = threadIdx.x, ty = threadIdx.y, lp = ty * BT_W + tx;
-    const int b = blockIdx.z, h = a.h, w = a.w;
+    const int b = bz, h = a.h, w = a.w;
     const long hw = (long)h * w;
-    const int gx = blockIdx.x * (BT_W - 4) + tx - 2, gy = blockIdx.y * (BT_H - 4) + ty - 2;
+    const int gx = bx * (BT_W - 4) + tx - 2, gy = by * (BT_H - 4) + ty - 2;
     const int rx = reflect_idx(gx, w), ry = reflect_idx(gy, h);
     const bool usable = rx >= 0 && rx < w && ry >= 0 && ry < h;
     const bool inimg = gx >= 0 && gx < w && gy >= 0 && gy < h;
@@ -390,7 +416,7 @@ __global__ void __launch_bounds__(BT_N, DENSE ? 6 : 1) photo_bwd_kernel(PhotoBwd
     for (int c = 0; c < 3; ++c) sA[c * BT_N + lp] = usable ? a.A[((long)b * 3 + c) * hw + pix] : 0.f;
     const float d = usable ? a.depth[b * hw + pix] : 1.f;
     float dd = 0.f;   // d loss / d depth at this pixel
-    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int blk = (bz * gdy + by) * gdx + bx;
     __shared__ Cam scam[NCTX];       // camera matrices per (sample, context): built by one thread each, read back as LDS broadcasts
 #pragma unroll
     for (int j = 0; j < NCTX; ++j)
@@ -518,6 +544,26 @@ __global__ void __launch_bounds__(BT_N, DENSE ? 6 : 1) photo_bwd_kernel(PhotoBwd
     }
 }
 
+template <int NCTX, bool DENSE = false>
+__global__ void __launch_bounds__(BT_N, DENSE ? 6 : 1) photo_bwd_kernel(PhotoBwdArgs a) {
+    photo_bwd_body<NCTX>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+struct PhotoBwdMulti {
+    PhotoBwdArgs a[PH_MAX_SCALES];
+    int first[PH_MAX_SCALES + 1];
+    int gdx[PH_MAX_SCALES], gdy[PH_MAX_SCALES];
+    int n;
+};
+
+template <int NCTX, bool DENSE>
+__global__ void __launch_bounds__(BT_N, DENSE ? 6 : 1) photo_bwd_multi_kernel(const PhotoBwdMulti m) {
+    int s = 0;
+    while (s + 1 < m.n && (int)blockIdx.x >= m.first[s + 1]) ++s;
+    const int local = blockIdx.x - m.first[s], gdx = m.gdx[s], gdy = m.gdy[s];
+    photo_bwd_body<NCTX>(m.a[s], local % gdx, (local / gdx) % gdy, local / (gdx * gdy), gdx, gdy);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stand-alone SSIM distance map (the callable module of ssim_loss.py:L6-53): out = clamp((1 - SSIM(x, y)) / 2, 0, 1) per pixel and channel,
 // ReflectionPad2d(1) + 3x3 mean, planar [B*C][H][W] fp32.  The training path evaluates SSIM inside photo_fwd / photo_bwd; this is the operator
@@ -635,6 +681,50 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* __res
     for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
     s = sde_block_sum(s, red);
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s * scale : s * scale;
+}
+
+// one workgroup per scale: out[s] = scale[s] * sum(partial_s[0..n_s))  (the same fixed order as reduce_partials_kernel: per-scale losses bit-identical)
+struct MultiReduce { const float* partial[PH_MAX_SCALES]; int n[PH_MAX_SCALES]; float scale[PH_MAX_SCALES]; };
+__global__ void __launch_bounds__(256) reduce_partials_multi_kernel(const MultiReduce r, float* __restrict__ out) {
+    __shared__ float red[16];
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < r.n[k]; i += 256) s += r.partial[k][i];
+    s = sde_block_sum(s, red);
+    if (threadIdx.x == 0) out[k] = s * r.scale[k];
+}
+
+// pose gradients of all scales: one wave per (sample, context) walks the scales' partial slabs in order (scale-by-scale, the order in which the
+// per-scale finalize launches used to accumulate)
+struct MultiPose { const float* partial[PH_MAX_SCALES]; int blocks_per_sample[PH_MAX_SCALES]; int n; };
+__global__ void pose_grad_finalize_multi_kernel(const MultiPose mp, int nctx, int B, float* __restrict__ dpose0, float* __restrict__ dpose1,
+                                                float* __restrict__ dpose2, float* __restrict__ dpose3) {
+    const int b = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    float tot[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) tot[i] = 0.f;
+    for (int s = 0; s < mp.n; ++s) {
+        float acc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+        const int bps = mp.blocks_per_sample[s];
+        for (int k = lane; k < bps; k += 64) {
+            const float* p = mp.partial[s] + (((long)b * bps + k) * nctx + j) * 12;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc[i] += p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) tot[i] += sde_wave_sum(acc[i]);
+    }
+    float* dp = j == 0 ? dpose0 : (j == 1 ? dpose1 : (j == 2 ? dpose2 : dpose3));
+    if (lane < 12) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s = lane == i ? tot[i] : s;
+        const int r = lane < 9 ? lane / 3 : lane - 9, c = lane < 9 ? lane % 3 : 3;
+        dp[b * 16 + r * 4 + c] = s;
+        if (lane < 4) dp[b * 16 + 12 + lane] = 0.f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1083,6 +1173,96 @@ int sde_photo_bwd(const sde_photo_desc* d, const float* const* sampled, const ui
                        d_pose[0], d->nctx > 1 ? d_pose[1] : nullptr, d->nctx > 2 ? d_pose[2] : nullptr, d->nctx > 3 ? d_pose[3] : nullptr,
                        accumulate_pose);
     SDE_CHECK_LAUNCH("sde_photo_bwd/finalize");
+    return SDE_OK;
+}
+
+static int fill_fwd_args(const sde_photo_desc* d, float* const* sampled, uint8_t* sel, float* partial, PhotoArgs& a) {
+    SDE_CHECK_ARG(d->A && d->depth && d->K && partial && sel, "sde_photo_multi_fwd: null pointer");
+    a.A = d->A; a.depth = d->depth; a.K = d->K; a.sel = sel; a.partial = partial; a.maps = nullptr; a.thr = nullptr;
+    for (int j = 0; j < SDE_MAX_CTX; ++j) {
+        a.ctx[j] = j < d->nctx ? d->ctx[j] : nullptr;
+        a.pose[j] = j < d->nctx ? d->pose[j] : nullptr;
+        a.sampled[j] = j < d->nctx ? sampled[j] : nullptr;
+        SDE_CHECK_ARG(j >= d->nctx || (a.ctx[j] && a.pose[j] && a.sampled[j]), "sde_photo_multi_fwd: null ctx / pose / sampled %d", j);
+    }
+    a.B = d->B; a.h = d->h; a.w = d->w; a.nctx = d->nctx; a.automask = d->automask; a.reduce_mean = d->reduce_mean;
+    a.sx = d->sx; a.sy = d->sy; a.ssim_w = d->ssim_w; a.C1 = d->C1; a.C2 = d->C2;
+    return SDE_OK;
+}
+
+int sde_photo_multi_fwd(const sde_photo_desc* d, int n, float* const* sampled, uint8_t* const* sel, float* const* partial, float* loss_out,
+                        sde_stream_t stream) {
+    SDE_CHECK_ARG(d && sampled && sel && partial && loss_out && n >= 1 && n <= PH_MAX_SCALES, "sde_photo_multi_fwd: bad argument (n=%d)", n);
+    PhotoMulti m;
+    MultiReduce r;
+    m.n = n; m.first[0] = 0;
+    for (int s = 0; s < n; ++s) {
+        SDE_CHECK_ARG(d[s].nctx == d[0].nctx && d[s].B == d[0].B && d[s].nctx >= 1 && d[s].nctx <= SDE_MAX_CTX && !d[s].clip_thr && d[s].B > 0 && d[s].h >= 4 && d[s].w >= 4,
+                      "sde_photo_multi_fwd: scale %d: same batch / contexts as scale 0, no clip thresholds, h, w >= 4", s);
+        int rc = fill_fwd_args(d + s, sampled + s * SDE_MAX_CTX, sel[s], partial[s], m.a[s]);
+        if (rc) return rc;
+        m.gdx[s] = sde_cdiv(d[s].w, FT_W - 2); m.gdy[s] = sde_cdiv(d[s].h, FT_H - 2);
+        m.first[s + 1] = m.first[s] + m.gdx[s] * m.gdy[s] * d[s].B;
+        r.partial[s] = partial[s]; r.n[s] = m.gdx[s] * m.gdy[s] * d[s].B; r.scale[s] = 1.0f / ((float)d[s].B * d[s].h * d[s].w);
+    }
+    for (int s = n; s < PH_MAX_SCALES; ++s) { m.gdx[s] = m.gdy[s] = 1; m.first[s + 1] = m.first[n]; r.partial[s] = nullptr; r.n[s] = 0; r.scale[s] = 0.f; m.a[s] = m.a[0]; }
+    const dim3 grid(m.first[n]), blk(FT_W, FT_H);
+    const size_t lds = photo_fwd_lds(d[0].nctx);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d[0].nctx) {
+        case 1: hipLaunchKernelGGL(photo_fwd_multi_kernel<1>, grid, blk, lds, st, m); break;
+        case 2: hipLaunchKernelGGL(photo_fwd_multi_kernel<2>, grid, blk, lds, st, m); break;
+        case 3: hipLaunchKernelGGL(photo_fwd_multi_kernel<3>, grid, blk, lds, st, m); break;
+        default: hipLaunchKernelGGL(photo_fwd_multi_kernel<4>, grid, blk, lds, st, m); break;
+    }
+    SDE_CHECK_LAUNCH("sde_photo_multi_fwd");
+    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(n), dim3(256), 0, st, r, loss_out);
+    SDE_CHECK_LAUNCH("sde_photo_multi_fwd/reduce");
+    return SDE_OK;
+}
+
+int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* sampled, const uint8_t* const* sel, const float* gout, float* const* d_depth,
+                        float* const* pose_partial, float* const* d_pose, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && sampled && sel && gout && d_depth && pose_partial && d_pose && n >= 1 && n <= PH_MAX_SCALES, "sde_photo_multi_bwd: bad argument (n=%d)", n);
+    PhotoBwdMulti m;
+    MultiPose mp;
+    m.n = mp.n = n; m.first[0] = 0;
+    for (int s = 0; s < n; ++s) {
+        const sde_photo_desc& ds = d[s];
+        SDE_CHECK_ARG(ds.nctx == d[0].nctx && ds.B == d[0].B && ds.nctx >= 1 && ds.nctx <= SDE_MAX_CTX && !ds.clip_thr && ds.A && ds.depth && ds.K && d_depth[s] && pose_partial[s] &&
+                      (ds.reduce_mean || sel[s]), "sde_photo_multi_bwd: scale %d: bad descriptor", s);
+        PhotoBwdArgs& a = m.a[s];
+        a.A = ds.A; a.depth = ds.depth; a.K = ds.K; a.sel = sel[s]; a.gout = gout + s; a.d_depth = d_depth[s]; a.pose_partial = pose_partial[s];
+        for (int j = 0; j < SDE_MAX_CTX; ++j) {
+            a.ctx[j] = j < ds.nctx ? ds.ctx[j] : nullptr;
+            a.pose[j] = j < ds.nctx ? ds.pose[j] : nullptr;
+            a.sampled[j] = j < ds.nctx ? sampled[s * SDE_MAX_CTX + j] : nullptr;
+            SDE_CHECK_ARG(j >= ds.nctx || (a.ctx[j] && a.pose[j] && a.sampled[j] && d_pose[j]), "sde_photo_multi_bwd: null ctx / pose / sampled %d", j);
+        }
+        a.B = ds.B; a.h = ds.h; a.w = ds.w; a.nctx = ds.nctx; a.automask = ds.automask; a.reduce_mean = ds.reduce_mean; a.accumulate = 0; a.clip = 0;
+        a.sx = ds.sx; a.sy = ds.sy; a.ssim_w = ds.ssim_w; a.C1 = ds.C1; a.C2 = ds.C2;
+        a.gscale = 1.0f / ((float)ds.B * ds.h * ds.w);
+        m.gdx[s] = sde_cdiv(ds.w, BT_W - 4); m.gdy[s] = sde_cdiv(ds.h, BT_H - 4);
+        m.first[s + 1] = m.first[s] + m.gdx[s] * m.gdy[s] * ds.B;
+        mp.partial[s] = pose_partial[s]; mp.blocks_per_sample[s] = m.gdx[s] * m.gdy[s];
+    }
+    for (int s = n; s < PH_MAX_SCALES; ++s) { m.gdx[s] = m.gdy[s] = 1; m.first[s + 1] = m.first[n]; m.a[s] = m.a[0]; mp.partial[s] = nullptr; mp.blocks_per_sample[s] = 0; }
+    const dim3 grid(m.first[n]), blk(BT_W, BT_H);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = photo_bwd_lds();
+    switch (d[0].nctx) {
+        case 1: hipLaunchKernelGGL((photo_bwd_multi_kernel<1, false>), grid, blk, lds, st, m); break;
+        case 2:
+            if (m.first[n] >= 1024) hipLaunchKernelGGL((photo_bwd_multi_kernel<2, true>), grid, blk, lds, st, m);
+            else hipLaunchKernelGGL((photo_bwd_multi_kernel<2, false>), grid, blk, lds, st, m);
+            break;
+        case 3: hipLaunchKernelGGL((photo_bwd_multi_kernel<3, false>), grid, blk, lds, st, m); break;
+        default: hipLaunchKernelGGL((photo_bwd_multi_kernel<4, false>), grid, blk, lds, st, m); break;
+    }
+    SDE_CHECK_LAUNCH("sde_photo_multi_bwd");
+    hipLaunchKernelGGL(pose_grad_finalize_multi_kernel, dim3(d[0].B, d[0].nctx), dim3(64), 0, st, mp, d[0].nctx, d[0].B, d_pose[0], d[0].nctx > 1 ? d_pose[1] : nullptr,
+                       d[0].nctx > 2 ? d_pose[2] : nullptr, d[0].nctx > 3 ? d_pose[3] : nullptr);
+    SDE_CHECK_LAUNCH("sde_photo_multi_bwd/finalize");
     return SDE_OK;
 }
 

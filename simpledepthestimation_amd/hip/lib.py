@@ -34,6 +34,8 @@ _PROTOS = {
     "sde_photo_num_blocks": ([_I, _I, _I, _I], c_int),
     "sde_photo_fwd": ([POINTER(PhotoDesc), POINTER(c_void_p), _P, _P, _P, _P, _F, _I, _P], c_int),
     "sde_photo_bwd": ([POINTER(PhotoDesc), POINTER(c_void_p), _P, _P, _F, _P, _I, _P, POINTER(c_void_p), _I, _P], c_int),
+    "sde_photo_multi_fwd": ([_P, _I, _P, _P, _P, _P, _P], c_int),
+    "sde_photo_multi_bwd": ([_P, _I, _P, _P, _P, _P, _P, _P, _P], c_int),
     "sde_ssim_fwd": ([_P, _P, _I, _I, _I, _I, _F, _F, _P, _P], c_int),
     "sde_ssim_bwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P], c_int),
     "sde_smooth_num_blocks": ([_I, _I, _I], c_int),

@@ -140,6 +140,98 @@ def photometric_scale_loss(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-
                              float(clip), len(ctxs), *ctxs, *poses)
 
 
+PH_MAX_SCALES = 4     # PH_MAX_SCALES of csrc/photometric.hip
+
+
+class _PhotoMulti(torch.autograd.Function):
+    """Every scale of MonoDepth2's photometric loss (MonoDepth2.py:L78-112) in one launch per phase: returns the [n] per-scale means."""
+
+    @staticmethod
+    def forward(ctx, K, ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales, *rest):
+        depths, As = rest[:n], rest[n:2 * n]
+        ctxs = rest[2 * n:2 * n + n * nctx]               # scale-major
+        poses = rest[2 * n + n * nctx:]
+        K = _f32c(K)
+        depths = [_f32c(d) for d in depths]; As = [_f32c(a) for a in As]
+        ctxs = [_f32c(c) for c in ctxs]; poses = [_f32c(p) for p in poses]
+        dev = K.device
+        lib = L.lib()
+        B = depths[0].shape[0]
+        descs = (L.PhotoDesc * n)()
+        sampled, sels, partials = [], [], []
+        samp_arr = (ctypes.c_void_p * (n * L.MAX_CTX))()
+        sel_arr, part_arr = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        for s in range(n):
+            _, _, h, w = depths[s].shape
+            sx, sy = scales[s]
+            d = _desc(As[s], ctxs[s * nctx:(s + 1) * nctx], poses, depths[s], K, sx, sy, ssim_w, C1, C2, automask, reduce_mean)
+            ctypes.memmove(ctypes.byref(descs, s * ctypes.sizeof(L.PhotoDesc)), ctypes.byref(d), ctypes.sizeof(L.PhotoDesc))
+            sm = [torch.empty(B, 3, h, w, device=dev) for _ in range(nctx)]
+            for j, t in enumerate(sm):
+                samp_arr[s * L.MAX_CTX + j] = t.data_ptr()
+            sampled += sm
+            sels.append(torch.empty(B, h, w, device=dev, dtype=torch.uint8)); sel_arr[s] = sels[-1].data_ptr()
+            partials.append(torch.empty(lib.sde_photo_num_blocks(B, h, w, 0), device=dev)); part_arr[s] = partials[-1].data_ptr()
+        loss = torch.empty(n, device=dev)
+        h0, w0 = depths[0].shape[-2:]
+        nbytes = sum(B * d.shape[-2] * d.shape[-1] * (16 + 12 * nctx) for d in depths)
+        L.timed("photo_fwd", nbytes, nctx, lambda: L.check(lib.sde_photo_multi_fwd(descs, n, samp_arr, sel_arr, part_arr, L.ptr(loss), L.stream()), "sde_photo_multi_fwd"),
+                dict(B=B, h=h0, w=w0, scales=n))
+        ctx.save_for_backward(K, *depths, *As, *ctxs, *poses, *sampled, *sels)
+        ctx.cfg = (ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales = ctx.cfg
+        t = ctx.saved_tensors
+        K = t[0]
+        o = 1
+        depths = t[o:o + n]; o += n
+        As = t[o:o + n]; o += n
+        ctxs = t[o:o + n * nctx]; o += n * nctx
+        poses = t[o:o + nctx]; o += nctx
+        sampled = t[o:o + n * nctx]; o += n * nctx
+        sels = t[o:o + n]
+        dev = K.device
+        lib = L.lib()
+        B = depths[0].shape[0]
+        descs = (L.PhotoDesc * n)()
+        samp_arr = (ctypes.c_void_p * (n * L.MAX_CTX))()
+        sel_arr, dd_arr, pp_arr = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        d_depths, pps = [], []
+        for s in range(n):
+            _, _, h, w = depths[s].shape
+            sx, sy = scales[s]
+            d = _desc(As[s], ctxs[s * nctx:(s + 1) * nctx], poses, depths[s], K, sx, sy, ssim_w, C1, C2, automask, reduce_mean)
+            ctypes.memmove(ctypes.byref(descs, s * ctypes.sizeof(L.PhotoDesc)), ctypes.byref(d), ctypes.sizeof(L.PhotoDesc))
+            for j in range(nctx):
+                samp_arr[s * L.MAX_CTX + j] = sampled[s * nctx + j].data_ptr()
+            sel_arr[s] = sels[s].data_ptr()
+            d_depths.append(torch.empty_like(depths[s])); dd_arr[s] = d_depths[-1].data_ptr()
+            pps.append(torch.empty(lib.sde_photo_num_blocks(B, h, w, 1) * nctx * 12, device=dev)); pp_arr[s] = pps[-1].data_ptr()
+        d_pose = [torch.empty(B, 4, 4, device=dev) for _ in range(nctx)]
+        gout = _f32c(gout)
+        h0, w0 = depths[0].shape[-2:]
+        nbytes = sum(B * d.shape[-2] * d.shape[-1] * (21 + 24 * nctx) for d in depths)
+        L.timed("photo_bwd", nbytes, nctx, lambda: L.check(lib.sde_photo_multi_bwd(descs, n, samp_arr, sel_arr, L.ptr(gout), dd_arr, pp_arr, L.ptr_array(d_pose), L.stream()),
+                                                          "sde_photo_multi_bwd"), dict(B=B, h=h0, w=w0, scales=n))
+        return (None,) * 9 + tuple(d_depths) + (None,) * n + (None,) * (n * nctx) + tuple(d_pose)
+
+
+def photometric_multi_loss(depths, K, As, ctxs_per_scale, poses, scales, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):
+    """All scales in one launch per phase.  depths / As: per scale; ctxs_per_scale[s]: the context frames at scale s; scales[s] = (w_s / W, h_s / H).
+    Returns a [n] tensor: photometric_scale_loss of every scale (no LOSS.CLIP: that option keeps the per-scale path)."""
+    if reduce not in ("min", "mean"):
+        raise NotImplementedError(reduce)
+    n, nctx = len(depths), len(poses)
+    if not (1 <= n <= PH_MAX_SCALES and len(As) == n and len(ctxs_per_scale) == n and all(len(c) == nctx for c in ctxs_per_scale)):
+        raise L.SdeHipError("photometric_multi_loss: 1-4 scales, one target and nctx context frames per scale")
+    flat_ctx = [c for cs in ctxs_per_scale for c in cs]
+    return _PhotoMulti.apply(K, float(ssim_w), float(C1), float(C2), bool(automask), reduce == "mean", n, nctx, tuple((float(a), float(b)) for a, b in scales),
+                             *depths, *As, *flat_ctx, *poses)
+
+
 def photometric_maps(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):
     """Forward only, exposing the individual maps / sampled frames / arg-min (tests, debugging)."""
     depth, K, A = _f32c(depth), _f32c(K), _f32c(A)

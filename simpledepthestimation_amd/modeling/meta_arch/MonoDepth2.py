@@ -16,6 +16,12 @@ from .build import META_ARCH_REGISTRY
 from .common import HipMetaArch
 
 
+# Every scale of the photometric loss in one launch per phase (sde_photo_multi_fwd / _bwd; bench.py --opt photo_multi=1).  Kernel time: forward 116 us against
+# 90 + 31 + 19 + 14, backward 187 against 148 + 50 + 22 + 17 (192x640, bs 12) -- but the replayed step measured SLOWER with it in two A/B pairs of one call
+# (MonoDepth2-R18 4.45 / 4.46 against 4.36 / 4.32 ms, R50 7.85 / 7.81 against 7.69 / 7.67), so the per-scale launches stay the default.
+MULTI_SCALE_PHOTO = False
+
+
 @META_ARCH_REGISTRY.register()
 class MonoDepth2Model(HipMetaArch):
     def __init__(self, cfg):
@@ -65,7 +71,9 @@ class MonoDepth2Model(HipMetaArch):
         num_scales = len(depth_pred)
         H, W = image.shape[-2:]
         terms = defaultdict(lambda: ([], []))        # loss name -> (per-scale 0-d tensors, their weights)
-        photo_losses = []
+        photo_losses, pyr = [], []
+        # every scale of the photometric loss in ONE launch per phase (sde_photo_multi_fwd / _bwd) unless LOSS.CLIP needs the per-scale statistics
+        multi = MULTI_SCALE_PHOTO and not (self.clip_loss and self.clip_loss > 0.0) and 1 <= num_scales <= HP.PH_MAX_SCALES
         for i in range(num_scales):
             scale_w = 1.0 / 2 ** (num_scales - i - 1)
             h, w = depth_pred[i].shape[-2:]
@@ -74,9 +82,11 @@ class MonoDepth2Model(HipMetaArch):
             else:
                 resized_image = HP.resize(image, (h, w))
                 resized_targets = [HP.resize(c, (h, w)) for c in contexts]
-            photo_losses.append(HP.photometric_scale_loss(depth_pred[i], intrinsics, resized_image, resized_targets, poses, w / W, h / H,
-                                                          ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2,
-                                                          automask=self.use_automask, reduce=self.photometric_reduce, clip=self.clip_loss))
+            pyr.append((resized_image, resized_targets, w / W, h / H))
+            if not multi:
+                photo_losses.append(HP.photometric_scale_loss(depth_pred[i], intrinsics, resized_image, resized_targets, poses, w / W, h / H,
+                                                              ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2,
+                                                              automask=self.use_automask, reduce=self.photometric_reduce, clip=self.clip_loss))
             def add(name, value, weight):
                 terms[name][0].append(value); terms[name][1].append(weight)
             if self.smooth_loss_w > 0.0:
@@ -88,6 +98,10 @@ class MonoDepth2Model(HipMetaArch):
                 add("var_loss", variance_loss(depth_pred[i]), scale_w * self.var_loss_w / num_scales)
         # the reference accumulates `loss += term_i * w_i` scale by scale (MonoDepth2.py:L103-112, L126): per loss that is 2 tiny kernels per scale forward
         # and as many backward; one stack + one dot product with a cached weight vector is the same sum (fp32, 4 terms) in 2 + 1 kernels
+        if multi:
+            photo_losses = HP.photometric_multi_loss(depth_pred, intrinsics, [p[0] for p in pyr], [p[1] for p in pyr], poses, [(p[2], p[3]) for p in pyr],
+                                                     ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2, automask=self.use_automask,
+                                                     reduce=self.photometric_reduce)
         output["rec_loss"] = self._weighted_sum(photo_losses, [1.0 / num_scales] * num_scales)
         for name, (vals, ws) in terms.items():
             output[name] = self._weighted_sum(vals, ws)

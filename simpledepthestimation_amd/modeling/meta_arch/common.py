@@ -22,10 +22,13 @@ class HipMetaArch(nn.Module):
     def _weighted_sum(self, values, weights):
         """sum_i weights[i] * values[i] of 0-d loss tensors as one stack + one dot product with a cached device vector.  The reference accumulates
         `loss += term_i * w_i` scale by scale: two tiny kernels per scale and loss forward, as many backward."""
-        key = (tuple(float(w) for w in weights), values[0].device, values[0].dtype)
+        v0 = values if torch.is_tensor(values) else values[0]
+        key = (tuple(float(w) for w in weights), v0.device, v0.dtype)
         cache = self.__dict__.setdefault("_wsum_cache", {})
         if key not in cache:      # built during the first (eager) step, before any hipGraph capture: no host-to-device copy inside a captured step
             cache[key] = torch.tensor(key[0], device=key[1], dtype=key[2])
+        if torch.is_tensor(values):       # already one [n] tensor (the multi-scale photometric launch): the dot product alone
+            return torch.dot(values, cache[key])
         return torch.dot(torch.stack([v.reshape(()) for v in values]), cache[key])
 
     def run_depth_net(self, batch):

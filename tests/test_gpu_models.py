@@ -375,6 +375,33 @@ def test_head_bias_fused_path_refuses_a_second_consumer_of_the_logit():
     assert torch.allclose(run(False), one)               # nothing stale is left behind by the refused backward
 
 
+def test_monodepth2_multi_scale_photometric_launch_equals_the_per_scale_launches():
+    """MonoDepth2Model with every scale of the photometric loss in one launch per phase (MULTI_SCALE_PHOTO) against one launch per scale: the same losses
+    bit for bit, the same gradients up to the order in which the pose gradients of the scales are summed."""
+    from simpledepthestimation_amd.modeling.meta_arch import MonoDepth2 as MD
+    sd = OM.init_state_dict(18, with_pose=True, seed=7)
+    batch = mono_batch(2, 64, 192, 21)
+    res = []
+    for multi in (False, True):
+        MD.MULTI_SCALE_PHOTO = multi
+        try:
+            model = build("MonoDepth2Model", 18, sd).train()
+            out = model(clone_batch(batch))
+            (out["rec_loss"] + out["smooth_loss"]).backward()
+            torch.cuda.synchronize()
+            res.append((float(out["rec_loss"]), float(out["smooth_loss"]), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            MD.MULTI_SCALE_PHOTO = False
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    norms = sorted(float(g.norm()) for g in res[0][2].values())
+    floor = 1e-3 * norms[len(norms) // 2]      # a conv bias in front of a GroupNorm has a zero gradient in exact arithmetic: rounding noise on both sides
+    for n in res[0][2]:
+        if n.startswith("pose_net.") and n.endswith(".0.bias"):
+            continue        # conv bias in front of GroupNorm: exactly zero gradient, what is computed is cancellation noise of the (re-ordered) pose-gradient sums
+        a, b = res[1][2][n].double(), res[0][2][n].double()
+        assert float((a - b).norm() / (b.norm() + floor)) < 1e-4, n
+
+
 def test_graph_replay_equals_eager():
     """The captured hipGraph step (zero-grad + batched weight pack + forward + backward) reproduces the eager step bit for bit."""
     from simpledepthestimation_amd.engine.trainer import supervised_trainer

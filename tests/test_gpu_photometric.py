@@ -169,6 +169,44 @@ def test_photometric_backward(P, B, h, w, scale, automask, reduce):
         assert rel < 5e-3, f"d_pose[{j}] relative L2 error {rel:.3e}"
 
 
+@pytest.mark.parametrize("automask,reduce", [(True, "min"), (False, "min"), (True, "mean")])
+@pytest.mark.parametrize("B,H,W,n", [(2, 64, 192, 4), (1, 40, 72, 3), (3, 32, 96, 2), (2, 16, 24, 1)])
+def test_photometric_all_scales_in_one_launch(P, B, H, W, n, automask, reduce):
+    """sde_photo_multi_fwd / _bwd (MonoDepth2.py:L78-112: the loop over the decoder scales as one launch per phase) against n calls of the single-scale
+    entry points: per-scale losses and depth gradients bit-identical (same workgroup body, same partial order), pose gradients = their sum over the scales."""
+    g = torch.Generator().manual_seed(B * 100 + n)
+    scales, cases = [], []
+    for i in range(n):
+        h, w = H >> i, W >> i
+        A, ctxs, D, Kfull, poses = _photo_case(B, h, w, 30 + i, scale=h / H)
+        cases.append((A, ctxs, D))
+        scales.append((w / W, h / H))
+    _, _, _, Kfull, poses = _photo_case(B, H, W, 30, 1.0)
+    K = Kfull.to(dev)
+    wts = torch.rand(n, generator=g) + 0.5
+
+    def run(multi):
+        Ds = [c[2].clone().to(dev).requires_grad_(True) for c in cases]
+        pd = [p.clone().to(dev).requires_grad_(True) for p in poses]
+        As = [c[0].to(dev) for c in cases]
+        Cs = [[x.to(dev) for x in c[1]] for c in cases]
+        if multi:
+            losses = P.photometric_multi_loss(Ds, K, As, Cs, pd, scales, automask=automask, reduce=reduce)
+        else:
+            losses = torch.stack([P.photometric_scale_loss(Ds[i], K, As[i], Cs[i], pd, scales[i][0], scales[i][1], automask=automask, reduce=reduce) for i in range(n)])
+        (losses * wts.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        return losses.detach().cpu(), [d.grad.cpu() for d in Ds], [q.grad.cpu() for q in pd]
+    l1, g1, p1 = run(False)
+    lm, gm, pm = run(True)
+    assert torch.equal(lm, l1), (lm, l1)
+    for i in range(n):
+        assert torch.equal(gm[i], g1[i]), f"d_depth of scale {i} differs"
+    for j in range(2):
+        close(pm[j][:, :3], p1[j][:, :3], 1e-5, 1e-6 * float(p1[j].abs().max()))
+        assert (pm[j][:, 3] == 0).all()
+
+
 def test_photometric_full_size_properties(P):
     """BASELINE size B=12, 192x640: size-independent properties (too slow for the oracle's autograd in CI seconds)."""
     B, h, w = 12, 192, 640
