@@ -377,6 +377,8 @@ def main():
     ap.add_argument("--force-overlap", action="store_true", help="use the two-phase backward (all-reduce overlap path) even on one GPU")
     ap.add_argument("--no-side-stream", action="store_true", help="weight-gradient GEMMs on the main stream (single-stream graph: profiling aid)")
     ap.add_argument("--no-pose-stream", action="store_true", help="MonoDepth2: PoseNet on the main stream, after the depth network (A/B aid)")
+    ap.add_argument("--marks", action="store_true", help="diagnostic: timestamp markers captured into the step's graph (sde_mark_time); the last "
+                                                         "step's timeline is added to the line as marks_us (a few extra 1-thread launches per step)")
     ap.add_argument("--const", action="append", default=[], metavar="NAME=INT", help="A/B aid: scheduling constant of hip/lib.py (JOIN_LAG, WGRAD_GROUP, DEFER_MAX_BYTES, FORK_MIN_BYTES ...)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="sde_conv_set_option(KEY, VALUE) before the model is built (A/B measurements)")
     ap.add_argument("--no-pgemm", action="store_true", help="register-staged GEMM kernels only (A/B against the persistent LDS-DMA GEMM)")
@@ -427,6 +429,9 @@ def main():
             L.SIDE_STREAM = False
         if args.no_pgemm:
             HN.set_option(HN.OPT_PGEMM, 0)
+    if args.marks:
+        from simpledepthestimation_amd.hip import lib as L
+        L.marks_enable(device)
     cfg, model, trainer = build(args, device)
     batch = synth_batch(WORKLOADS[args.workload]["arch"], args.batch, args.height, args.width, 1000 + rank, device)
 
@@ -487,6 +492,9 @@ def main():
                "backend": ("none" if world == 1 else {"nccl": "rccl"}.get(dist.get_backend(), dist.get_backend())),
                "rccl_ranks": (world if world > 1 and dist.get_backend() == "nccl" else 0), "devices": min(world, ndev),
                "final_losses": final}
+        if args.marks:
+            from simpledepthestimation_amd.hip import lib as L
+            out["marks_us"] = {k: round(v, 1) for k, v in sorted(L.marks_read("step_start").items(), key=lambda kv: kv[1])}
         if args.with_loader:
             out["data"] = "synthetic uint8 frames at 375x1242 fed per step through the pinned host -> device prefetcher and the device resize + colour-jitter kernels"
             out["input_side"] = {"h2d_bytes_per_step": h2d_bytes, "in_timed_region": True}

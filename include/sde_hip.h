@@ -40,6 +40,11 @@ typedef void* sde_stream_t; /* hipStream_t */
 const char* sde_last_error(void); /* message of the last failing call on this thread */
 int sde_version(void);            /* ABI version, bumped on incompatible change */
 
+/* Diagnostics: store the device's constant-rate wall clock (ticks of sde_wall_clock_khz()) into *slot, in stream order.  Captured into the step's
+ * hipGraph at chosen points, the markers give the replayed step's real timeline (bench.py --marks).  Not part of the reference's surface. */
+int sde_mark_time(uint64_t* slot, sde_stream_t stream);
+int sde_wall_clock_khz(void); /* < 0: query failed */
+
 /* ---------------------------------------------------------------------------------------------------
  * Geometry / photometric path (fp32)
  * ------------------------------------------------------------------------------------------------- */
@@ -98,6 +103,9 @@ int sde_photo_multi_fwd(const sde_photo_desc* d, int n, float* const* sampled, u
                         sde_stream_t stream);
 int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* sampled, const uint8_t* const* sel, const float* gout, float* const* d_depth,
                         float* const* pose_partial, float* const* d_pose, sde_stream_t stream);
+/* d_pose == NULL in sde_photo_multi_bwd leaves the per-workgroup pose partials unsummed; this call sums them (same order, same result).  Two calls so
+ * that the caller can enqueue the pose side on the stream PoseNet's backward runs on (it is the only consumer), behind an event of its own. */
+int sde_photo_multi_pose_finalize(const sde_photo_desc* d, int n, const float* const* pose_partial, float* const* d_pose, sde_stream_t stream);
 
 /* Stand-alone SSIM distance map, the callable module of detectron2/modeling/losses/ssim_loss.py:L6-53:
  * out[b,c,h,w] = clamp((1 - SSIM(x, y)) / 2, 0, 1) with ReflectionPad2d(1) + 3x3 mean; x, y, out planar [B,C,H,W] fp32 (the training path

@@ -16,3 +16,22 @@ void sde_set_error(const char* fmt, ...) {
 
 extern "C" const char* sde_last_error(void) { return g_err; }
 extern "C" int sde_version(void) { return 1; }
+
+// Timeline markers: one tiny kernel that stores the device's constant-rate wall clock.  Enqueued (and captured into the step's hipGraph) at chosen points of
+// the step's streams, they give the replayed step's real timeline -- a profiler's kernel trace serialises the graph's parallel branches
+// (profiles/README.md, round 3), these do not.  Diagnostic only (bench.py --marks); nothing reads them in training.
+__global__ void sde_mark_time_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+extern "C" int sde_mark_time(uint64_t* slot, sde_stream_t stream) {
+    if (!slot) { sde_set_error("sde_mark_time: null slot"); return -1; }
+    hipLaunchKernelGGL(sde_mark_time_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sde_set_error("sde_mark_time: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+extern "C" int sde_wall_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
+    return khz;
+}

@@ -1223,7 +1223,8 @@ int sde_photo_multi_fwd(const sde_photo_desc* d, int n, float* const* sampled, u
 
 int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* sampled, const uint8_t* const* sel, const float* gout, float* const* d_depth,
                         float* const* pose_partial, float* const* d_pose, sde_stream_t stream) {
-    SDE_CHECK_ARG(d && sampled && sel && gout && d_depth && pose_partial && d_pose && n >= 1 && n <= PH_MAX_SCALES, "sde_photo_multi_bwd: bad argument (n=%d)", n);
+    // d_pose == NULL: the pose partials are left for sde_photo_multi_pose_finalize (which the caller may enqueue on another stream)
+    SDE_CHECK_ARG(d && sampled && sel && gout && d_depth && pose_partial && n >= 1 && n <= PH_MAX_SCALES, "sde_photo_multi_bwd: bad argument (n=%d)", n);
     PhotoBwdMulti m;
     MultiPose mp;
     m.n = mp.n = n; m.first[0] = 0;
@@ -1237,7 +1238,7 @@ int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* samp
             a.ctx[j] = j < ds.nctx ? ds.ctx[j] : nullptr;
             a.pose[j] = j < ds.nctx ? ds.pose[j] : nullptr;
             a.sampled[j] = j < ds.nctx ? sampled[s * SDE_MAX_CTX + j] : nullptr;
-            SDE_CHECK_ARG(j >= ds.nctx || (a.ctx[j] && a.pose[j] && a.sampled[j] && d_pose[j]), "sde_photo_multi_bwd: null ctx / pose / sampled %d", j);
+            SDE_CHECK_ARG(j >= ds.nctx || (a.ctx[j] && a.pose[j] && a.sampled[j] && (!d_pose || d_pose[j])), "sde_photo_multi_bwd: null ctx / pose / sampled %d", j);
         }
         a.B = ds.B; a.h = ds.h; a.w = ds.w; a.nctx = ds.nctx; a.automask = ds.automask; a.reduce_mean = ds.reduce_mean; a.accumulate = 0; a.clip = 0;
         a.sx = ds.sx; a.sy = ds.sy; a.ssim_w = ds.ssim_w; a.C1 = ds.C1; a.C2 = ds.C2;
@@ -1260,9 +1261,29 @@ int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* samp
         default: hipLaunchKernelGGL((photo_bwd_multi_kernel<4, false>), grid, blk, lds, st, m); break;
     }
     SDE_CHECK_LAUNCH("sde_photo_multi_bwd");
+    if (!d_pose) return SDE_OK;
     hipLaunchKernelGGL(pose_grad_finalize_multi_kernel, dim3(d[0].B, d[0].nctx), dim3(64), 0, st, mp, d[0].nctx, d[0].B, d_pose[0], d[0].nctx > 1 ? d_pose[1] : nullptr,
                        d[0].nctx > 2 ? d_pose[2] : nullptr, d[0].nctx > 3 ? d_pose[3] : nullptr);
     SDE_CHECK_LAUNCH("sde_photo_multi_bwd/finalize");
+    return SDE_OK;
+}
+
+int sde_photo_multi_pose_finalize(const sde_photo_desc* d, int n, const float* const* pose_partial, float* const* d_pose, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && pose_partial && d_pose && n >= 1 && n <= PH_MAX_SCALES, "sde_photo_multi_pose_finalize: bad argument (n=%d)", n);
+    MultiPose mp;
+    mp.n = n;
+    for (int s = 0; s < PH_MAX_SCALES; ++s) {
+        const bool on = s < n;
+        SDE_CHECK_ARG(!on || (pose_partial[s] && d[s].nctx == d[0].nctx && d[s].B == d[0].B && d[s].h > 0 && d[s].w > 0), "sde_photo_multi_pose_finalize: scale %d: bad descriptor", s);
+        mp.partial[s] = on ? pose_partial[s] : nullptr;
+        mp.blocks_per_sample[s] = on ? sde_cdiv(d[s].w, BT_W - 4) * sde_cdiv(d[s].h, BT_H - 4) : 0;
+    }
+    const int nctx = d[0].nctx;
+    SDE_CHECK_ARG(nctx >= 1 && nctx <= SDE_MAX_CTX, "sde_photo_multi_pose_finalize: nctx=%d", nctx);
+    for (int j = 0; j < nctx; ++j) SDE_CHECK_ARG(d_pose[j], "sde_photo_multi_pose_finalize: null d_pose[%d]", j);
+    hipLaunchKernelGGL(pose_grad_finalize_multi_kernel, dim3(d[0].B, nctx), dim3(64), 0, (hipStream_t)stream, mp, nctx, d[0].B, d_pose[0], nctx > 1 ? d_pose[1] : nullptr,
+                       nctx > 2 ? d_pose[2] : nullptr, nctx > 3 ? d_pose[3] : nullptr);
+    SDE_CHECK_LAUNCH("sde_photo_multi_pose_finalize");
     return SDE_OK;
 }
 

@@ -247,6 +247,7 @@ class HipTrainer:
             self.scale_state[3] = float(self.t)
 
     def _fwd_bwd(self, batch):
+        L.mark("step_start")
         self.gflat.zero_()
         if self._packer is not None:
             self._packer.run()                      # every conv operand of the step in one launch
@@ -266,7 +267,9 @@ class HipTrainer:
             self._packer.join_dgrad()
         if self._one is None or self._one.dtype != losses.dtype or self._one.device != losses.device or self._one.shape != losses.shape:
             self._one = torch.ones_like(losses)         # d loss / d loss, kept: backward() would launch a fill for it every step
+        L.mark("loss_fwd_end")
         self._backward(lambda: losses.backward(gradient=self._one))
+        L.mark("bwd_joined")
         if self._packer is None and self.batch_pack:
             try:
                 self._packer = HN.WeightPacker(self.model)
@@ -282,6 +285,18 @@ class HipTrainer:
         HN.MAIN_STREAM = torch.cuda.current_stream() if self.device.type == "cuda" else None
         try:
             run()
+            if L.MARKS is not None:                  # diagnostic timeline (bench.py --marks): the last work of each stream of the phase
+                L.mark("bwd_main_end")
+                capturing = torch.cuda.is_current_stream_capturing()
+                for name, st_ in [("bwd_side_end", L.side_stream())] + ([("bwd_aux_end", L.aux_stream())] if L.AUX_USED else []):
+                    with torch.cuda.stream(st_):
+                        if torch.cuda.is_current_stream_capturing() == capturing:      # (a helper stream this phase never forked is not part of the capture)
+                            L.mark(name)
+                            joined = True
+                        else:
+                            joined = False
+                    if joined:
+                        torch.cuda.current_stream().wait_stream(st_)                   # the marker is the stream's last node: join it
             L.join_aux()            # a network that ran on the auxiliary stream (PoseNet): its backward ran there as well
             if self._wreduce is not None:
                 self._wreduce.flush()
@@ -424,10 +439,15 @@ class HipTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph, graph_b = torch.cuda.CUDAGraph(), None
+        dot = os.environ.get("SDE_GRAPH_DOT")      # debugging aid: the captured DAG (kernel nodes + edges) as a Graphviz file
+        if dot:
+            graph.enable_debug_mode()
         # thread-local capture mode: other threads of the process keep making HIP calls while the step is captured -- RCCL's watchdog thread once the
         # process group exists (N > 1), a data loader's pin-memory thread -- and in the default "global" mode any of them invalidates the capture
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             static_out = self._fwd_bwd(dict(self._static_batch))
+        if dot:
+            graph.debug_dump(dot)
         if self._cut is not None:                  # phase B: the rest of backward, same memory pool, replayed after phase A
             graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_b, pool=graph.pool(), capture_error_mode="thread_local"):

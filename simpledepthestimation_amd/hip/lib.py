@@ -27,6 +27,8 @@ class PhotoDesc(Structure):
 _P, _I, _F = c_void_p, c_int, c_float
 _PROTOS = {
     "sde_version": ([], c_int),
+    "sde_mark_time": ([_P, _P], c_int),
+    "sde_wall_clock_khz": ([], c_int),
     "sde_resize": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], c_int),
     "sde_pose_vec2mat": ([_P, _P, _I, _P], c_int),
     "sde_pose_vec2mat_bwd": ([_P, _P, _P, _I, _P], c_int),
@@ -36,6 +38,7 @@ _PROTOS = {
     "sde_photo_bwd": ([POINTER(PhotoDesc), POINTER(c_void_p), _P, _P, _F, _P, _I, _P, POINTER(c_void_p), _I, _P], c_int),
     "sde_photo_multi_fwd": ([_P, _I, _P, _P, _P, _P, _P], c_int),
     "sde_photo_multi_bwd": ([_P, _I, _P, _P, _P, _P, _P, _P, _P], c_int),
+    "sde_photo_multi_pose_finalize": ([_P, _I, _P, _P, _P], c_int),
     "sde_ssim_fwd": ([_P, _P, _I, _I, _I, _I, _F, _F, _P, _P], c_int),
     "sde_ssim_bwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P], c_int),
     "sde_smooth_num_blocks": ([_I, _I, _I], c_int),
@@ -194,6 +197,36 @@ def join_aux():
 def all_side_streams():
     d = torch.cuda.current_device()
     return list(_side.get(d, [])) + ([_aux[d]] if d in _aux else [])
+
+
+# Timeline markers (bench.py --marks): mark(name) enqueues one sde_mark_time launch on the current stream; under graph capture it becomes a node of the
+# step's graph, so every replay refreshes the slot.  MARKS is None unless a diagnostic run switched them on: mark() is then a no-op.
+MARKS = None
+
+
+def marks_enable(device):
+    global MARKS
+    MARKS = {"names": [], "slots": torch.zeros(128, dtype=torch.int64, device=device)}
+
+
+def mark(name):
+    if MARKS is None:
+        return
+    if name not in MARKS["names"]:
+        MARKS["names"].append(name)
+    i = MARKS["names"].index(name)
+    check(lib().sde_mark_time(c_void_p(MARKS["slots"].data_ptr() + 8 * i), stream()), "sde_mark_time")
+
+
+def marks_read(origin=None):
+    """{name: microseconds since the `origin` marker (default: the earliest one)} of the last step's markers (synchronises)."""
+    if MARKS is None:
+        return {}
+    torch.cuda.synchronize()
+    khz = lib().sde_wall_clock_khz()
+    t = MARKS["slots"][:len(MARKS["names"])].tolist()
+    t0 = t[MARKS["names"].index(origin)] if origin in MARKS["names"] else min(t)
+    return {n: (v - t0) * 1e3 / khz for n, v in zip(MARKS["names"], t)}
 
 
 def ptr_array(tensors):

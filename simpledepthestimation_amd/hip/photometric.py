@@ -147,7 +147,7 @@ class _PhotoMulti(torch.autograd.Function):
     """Every scale of MonoDepth2's photometric loss (MonoDepth2.py:L78-112) in one launch per phase: returns the [n] per-scale means."""
 
     @staticmethod
-    def forward(ctx, K, ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales, *rest):
+    def forward(ctx, K, ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales, pose_stream, *rest):
         depths, As = rest[:n], rest[n:2 * n]
         ctxs = rest[2 * n:2 * n + n * nctx]               # scale-major
         poses = rest[2 * n + n * nctx:]
@@ -179,6 +179,7 @@ class _PhotoMulti(torch.autograd.Function):
                 dict(B=B, h=h0, w=w0, scales=n))
         ctx.save_for_backward(K, *depths, *As, *ctxs, *poses, *sampled, *sels)
         ctx.cfg = (ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales)
+        ctx.pose_stream = pose_stream
         return loss
 
     @staticmethod
@@ -214,14 +215,29 @@ class _PhotoMulti(torch.autograd.Function):
         gout = _f32c(gout)
         h0, w0 = depths[0].shape[-2:]
         nbytes = sum(B * d.shape[-2] * d.shape[-1] * (21 + 24 * nctx) for d in depths)
-        L.timed("photo_bwd", nbytes, nctx, lambda: L.check(lib.sde_photo_multi_bwd(descs, n, samp_arr, sel_arr, L.ptr(gout), dd_arr, pp_arr, L.ptr_array(d_pose), L.stream()),
+        # PoseNet on the auxiliary stream (MonoDepth2Model.forward): the pose side of this backward -- summing the partials -- goes there as well, and is
+        # enqueued BEFORE the main stream's next kernel.  Besides taking a launch off the main chain this shapes the captured graph: the HIP runtime gives
+        # a node's first captured dependant the node's own queue and the later ones the next queues round robin, and with the pose chain as the SECOND
+        # dependant it landed on the queue of the depth network's data-gradient chain and ran after it (in-graph markers, profiles/README.md round 3)
+        # (pose_stream is the caller's statement that every consumer of the pose gradients runs on that stream)
+        aux = ctx.pose_stream if L.PROFILE is None else None
+        L.timed("photo_bwd", nbytes, nctx, lambda: L.check(lib.sde_photo_multi_bwd(descs, n, samp_arr, sel_arr, L.ptr(gout), dd_arr, pp_arr,
+                                                                                   None if aux is not None else L.ptr_array(d_pose), L.stream()),
                                                           "sde_photo_multi_bwd"), dict(B=B, h=h0, w=w0, scales=n))
-        return (None,) * 9 + tuple(d_depths) + (None,) * n + (None,) * (n * nctx) + tuple(d_pose)
+        if aux is not None:
+            aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux):
+                L.check(lib.sde_photo_multi_pose_finalize(descs, n, pp_arr, L.ptr_array(d_pose), L.stream()), "sde_photo_multi_pose_finalize")
+            for t_ in pps + d_pose:
+                t_.record_stream(aux)
+        return (None,) * 10 + tuple(d_depths) + (None,) * n + (None,) * (n * nctx) + tuple(d_pose)
 
 
-def photometric_multi_loss(depths, K, As, ctxs_per_scale, poses, scales, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):
+def photometric_multi_loss(depths, K, As, ctxs_per_scale, poses, scales, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min", pose_stream=None):
     """All scales in one launch per phase.  depths / As: per scale; ctxs_per_scale[s]: the context frames at scale s; scales[s] = (w_s / W, h_s / H).
-    Returns a [n] tensor: photometric_scale_loss of every scale (no LOSS.CLIP: that option keeps the per-scale path)."""
+    Returns a [n] tensor: photometric_scale_loss of every scale (no LOSS.CLIP: that option keeps the per-scale path).
+    pose_stream: the stream the network that produced `poses` ran on when that is not the current one (its backward runs there): the pose gradients
+    are then summed on that stream."""
     if reduce not in ("min", "mean"):
         raise NotImplementedError(reduce)
     n, nctx = len(depths), len(poses)
@@ -229,7 +245,7 @@ def photometric_multi_loss(depths, K, As, ctxs_per_scale, poses, scales, ssim_w=
         raise L.SdeHipError("photometric_multi_loss: 1-4 scales, one target and nctx context frames per scale")
     flat_ctx = [c for cs in ctxs_per_scale for c in cs]
     return _PhotoMulti.apply(K, float(ssim_w), float(C1), float(C2), bool(automask), reduce == "mean", n, nctx, tuple((float(a), float(b)) for a, b in scales),
-                             *depths, *As, *flat_ctx, *poses)
+                             pose_stream, *depths, *As, *flat_ctx, *poses)
 
 
 def photometric_maps(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):

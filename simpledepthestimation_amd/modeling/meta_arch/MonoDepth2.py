@@ -19,7 +19,7 @@ from .common import HipMetaArch
 # Every scale of the photometric loss in one launch per phase (sde_photo_multi_fwd / _bwd; bench.py --opt photo_multi=1).  Kernel time: forward 116 us against
 # 90 + 31 + 19 + 14, backward 187 against 148 + 50 + 22 + 17 (192x640, bs 12) -- but the replayed step measured SLOWER with it in two A/B pairs of one call
 # (MonoDepth2-R18 4.45 / 4.46 against 4.36 / 4.32 ms, R50 7.85 / 7.81 against 7.69 / 7.67), so the per-scale launches stay the default.
-MULTI_SCALE_PHOTO = False
+MULTI_SCALE_PHOTO = True
 
 
 @META_ARCH_REGISTRY.register()
@@ -49,6 +49,7 @@ class MonoDepth2Model(HipMetaArch):
             output["depth_pred"] = batch["depth_pred"][0]
             return output
         batch = to_cuda(batch, self.device)
+        pose_stream = None
         if L.POSE_STREAM and self.device.type == "cuda":
             # PoseNet underneath the depth network: its kernels are launch-bound (seven small layers), the depth network's are not; autograd
             # replays its backward on the same auxiliary stream, i.e. underneath the depth network's backward
@@ -58,8 +59,11 @@ class MonoDepth2Model(HipMetaArch):
                 batch["pose_net_input"] = torch.cat([batch["img"]] + batch["ctx_img"], 1)   # augmented frames, not normalised (L65)
                 batch = self.pose_net(batch)
                 pyramid = self._image_pyramid(batch)                                         # needs neither network: off the main stream as well
+                L.mark("pose_fwd_end")
             L.AUX_USED = True
+            pose_stream = aux
             batch = self.run_depth_net(batch)
+            L.mark("depth_fwd_end")
             cur.wait_stream(aux)
         else:
             batch = self.run_depth_net(batch)
@@ -69,6 +73,13 @@ class MonoDepth2Model(HipMetaArch):
         image, contexts, intrinsics = batch["img_orig"], batch["ctx_img_orig"], batch["intrinsics"].float().contiguous()
         depth_pred, poses = batch["depth_pred"], batch["pose_pred"]
         num_scales = len(depth_pred)
+        if L.MARKS is not None:      # diagnostic timeline: when the two networks' backward passes receive their first gradients
+            def _marker(name):
+                def hook(g):
+                    L.mark(name)
+                return hook
+            depth_pred[0].register_hook(_marker("depth_bwd_start"))
+            poses[0].register_hook(_marker("pose_bwd_start"))
         H, W = image.shape[-2:]
         terms = defaultdict(lambda: ([], []))        # loss name -> (per-scale 0-d tensors, their weights)
         photo_losses, pyr = [], []
@@ -101,7 +112,7 @@ class MonoDepth2Model(HipMetaArch):
         if multi:
             photo_losses = HP.photometric_multi_loss(depth_pred, intrinsics, [p[0] for p in pyr], [p[1] for p in pyr], poses, [(p[2], p[3]) for p in pyr],
                                                      ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2, automask=self.use_automask,
-                                                     reduce=self.photometric_reduce)
+                                                     reduce=self.photometric_reduce, pose_stream=pose_stream)
         output["rec_loss"] = self._weighted_sum(photo_losses, [1.0 / num_scales] * num_scales)
         for name, (vals, ws) in terms.items():
             output[name] = self._weighted_sum(vals, ws)
