@@ -107,6 +107,24 @@ int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* samp
  * that the caller can enqueue the pose side on the stream PoseNet's backward runs on (it is the only consumer), behind an event of its own. */
 int sde_photo_multi_pose_finalize(const sde_photo_desc* d, int n, const float* const* pose_partial, float* const* d_pose, sde_stream_t stream);
 
+/* The photometric AND the edge-aware smoothness term of every scale of MonoDepth2's loss loop (detectron2/modeling/meta_arch/MonoDepth2.py:L78-126,
+ * modeling/losses/smoothness_loss.py:L42-80) behind one call per pass.  d [n] as for sde_photo_multi_fwd (d[s].A doubles as the smoothness term's image,
+ * d[s].depth as its depth).  photo_w / smooth_w: host arrays [n] of the weights the reference multiplies each scale's term with (smooth_w NULL: no
+ * smoothness term, its buffers may be NULL).  Buffers per scale: sampled / sel / photo_partial as for sde_photo_multi_fwd; sm_mean_part [B*32], sm_dn [B*h*w],
+ * sm_loss_part / sm_s_part [sde_smooth_num_blocks].  per_scale [2n] receives every scale's photometric mean, then every scale's smoothness value
+ * (bit-identical to sde_photo_fwd / sde_smooth_fwd); totals [2] = the two weighted sums, accumulated in scale order.  ticket: one device int, zero on
+ * entry, left zero.  Backward: g_rec / g_smooth = device scalars, the upstream gradients of totals[0] / totals[1] (g_smooth NULL: photometric part only);
+ * d_depth [n] is written (photometric) and then accumulated (smoothness); pose side as in sde_photo_multi_bwd. */
+int sde_mono_loss_fwd(const sde_photo_desc* d, int n, const float* photo_w, const float* smooth_w, float* const* sampled, uint8_t* const* sel,
+                      float* const* photo_partial, float* const* sm_mean_part, float* const* sm_dn, float* const* sm_loss_part, float* const* sm_s_part,
+                      float* per_scale, float* totals, int* ticket, sde_stream_t stream);
+int sde_mono_loss_bwd(const sde_photo_desc* d, int n, const float* photo_w, const float* smooth_w, const float* const* sampled, const uint8_t* const* sel,
+                      const float* g_rec, const float* g_smooth, const float* const* sm_mean_part, const float* const* sm_dn, const float* const* sm_s_part,
+                      float* const* d_depth, float* const* pose_partial, float* const* d_pose, sde_stream_t stream);
+/* The smoothness half of sde_mono_loss_bwd on its own (a caller that forks the pose side to another stream between the two halves): d_depth[s] (+)= ... */
+int sde_smooth_multi_bwd(const sde_photo_desc* d, int n, const float* smooth_w, const float* g_smooth, const float* const* sm_mean_part, const float* const* sm_dn,
+                         const float* const* sm_s_part, float* const* d_depth, int accumulate, sde_stream_t stream);
+
 /* Stand-alone SSIM distance map, the callable module of detectron2/modeling/losses/ssim_loss.py:L6-53:
  * out[b,c,h,w] = clamp((1 - SSIM(x, y)) / 2, 0, 1) with ReflectionPad2d(1) + 3x3 mean; x, y, out planar [B,C,H,W] fp32 (the training path
  * evaluates SSIM inside sde_photo_fwd / sde_photo_bwd).  Backward: dx and/or dy (either may be NULL) for the upstream gradient gout [B,C,H,W];

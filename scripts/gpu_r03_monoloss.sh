@@ -1,0 +1,12 @@
+mkdir -p gpurun_out
+timeout -k 10 900 python -m pytest tests/test_gpu_photometric.py tests/test_gpu_models.py -q -x -k "photometric or monodepth2 or mono or smooth" > gpurun_out/r03w_tests.log 2>&1; rc=$?
+tail -3 gpurun_out/r03w_tests.log
+if [ $rc -ne 0 ]; then grep -E "Error|error|assert|FAILED" gpurun_out/r03w_tests.log | head -30; exit $rc; fi
+one() { timeout -k 10 120 python bench.py --no-cpu-baseline --profile-steps 0 --steps 60 --warmup 10 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
+{
+for wl in mono_r18 mono_r50; do
+echo "$wl fused loss / per-scale: $(one --workload $wl) $(one --workload $wl --opt photo_multi=0) $(one --workload $wl) $(one --workload $wl --opt photo_multi=0)"
+done
+echo "mono_r18 force-overlap: $(one --workload mono_r18 --force-overlap)  with-loader: $(one --workload mono_r18 --with-loader)"
+} > gpurun_out/r03w_monoloss.txt 2>&1
+cat gpurun_out/r03w_monoloss.txt

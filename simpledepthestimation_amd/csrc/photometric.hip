@@ -732,9 +732,8 @@ __global__ void pose_grad_finalize_multi_kernel(const MultiPose mp, int nctx, in
 // ------------------------------------------------------------------------------------------------
 constexpr int SM_CHUNKS = 32;   // partial sums per image for the inverse-depth mean
 
-__global__ void __launch_bounds__(256) smooth_mean_kernel(const float* __restrict__ depth, int hw, float* __restrict__ part /*[B][SM_CHUNKS]*/) {
+__device__ __forceinline__ void smooth_mean_body(const float* __restrict__ depth, int hw, float* __restrict__ part /*[B][SM_CHUNKS]*/, const int b, const int ch) {
     __shared__ float red[16];
-    const int b = blockIdx.y, ch = blockIdx.x;
     const int per = (hw + SM_CHUNKS - 1) / SM_CHUNKS;
     const int lo = ch * per, hi = min(hw, lo + per);
     float s = 0.f;
@@ -743,16 +742,20 @@ __global__ void __launch_bounds__(256) smooth_mean_kernel(const float* __restric
     if (threadIdx.x == 0) part[b * SM_CHUNKS + ch] = s;
 }
 
+__global__ void __launch_bounds__(256) smooth_mean_kernel(const float* __restrict__ depth, int hw, float* __restrict__ part) {
+    smooth_mean_body(depth, hw, part, blockIdx.y, blockIdx.x);
+}
+
 // forward + the upstream-independent part of the backward:
 //   dn[b,y,x] = d(loss)/d(normalised inverse depth), S partials = sum_q dn[q]*inv[q]
-__global__ void __launch_bounds__(256) smooth_fwd_kernel(const float* __restrict__ depth, const float* __restrict__ img,
-                                                         const float* __restrict__ mean_part, int B, int h, int w,
-                                                         float* __restrict__ dn, float* __restrict__ loss_part /*[nblk]*/,
-                                                         float* __restrict__ s_part /*[nblk]*/) {
+__device__ __forceinline__ void smooth_fwd_body(const float* __restrict__ depth, const float* __restrict__ img,
+                                                const float* __restrict__ mean_part, int B, int h, int w,
+                                                float* __restrict__ dn, float* __restrict__ loss_part /*[nblk]*/,
+                                                float* __restrict__ s_part /*[nblk]*/, const int bx, const int by, const int bz, const int gdx, const int gdy) {
     __shared__ float red[16];
-    const int b = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = bz;
+    const int x = bx * 64 + (threadIdx.x & 63);
+    const int y = by * 4 + (threadIdx.x >> 6);
     const long hw = (long)h * w;
     float m = 0.f;
     for (int i = 0; i < SM_CHUNKS; ++i) m += mean_part[b * SM_CHUNKS + i];
@@ -812,20 +815,25 @@ __global__ void __launch_bounds__(256) smooth_fwd_kernel(const float* __restrict
         if (dn) dn[b * hw + p] = g;
         sv = g * inv;
     }
-    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int blk = (bz * gdy + by) * gdx + bx;
     const float ls = sde_block_sum(loss, red);
     if (threadIdx.x == 0) loss_part[blk] = ls;
     const float ss = sde_block_sum(sv, red);
     if (threadIdx.x == 0 && s_part) s_part[blk] = ss;
 }
 
-__global__ void __launch_bounds__(256) smooth_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ dn,
-                                                         const float* __restrict__ mean_part, const float* __restrict__ s_part,
-                                                         int blocks_per_sample, const float* __restrict__ gout, float gscale,
-                                                         int h, int w, float* __restrict__ d_depth, int accumulate) {
+__global__ void __launch_bounds__(256) smooth_fwd_kernel(const float* __restrict__ depth, const float* __restrict__ img, const float* __restrict__ mean_part,
+                                                         int B, int h, int w, float* __restrict__ dn, float* __restrict__ loss_part, float* __restrict__ s_part) {
+    smooth_fwd_body(depth, img, mean_part, B, h, w, dn, loss_part, s_part, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+__device__ __forceinline__ void smooth_bwd_body(const float* __restrict__ depth, const float* __restrict__ dn,
+                                                const float* __restrict__ mean_part, const float* __restrict__ s_part,
+                                                int blocks_per_sample, const float* __restrict__ gout, float gscale,
+                                                int h, int w, float* __restrict__ d_depth, int accumulate, const int bx, const int by, const int bz) {
     __shared__ float sh[2];
     __shared__ float red[16];
-    const int b = blockIdx.z;
+    const int b = bz;
     const long hw = (long)h * w;
     // the sample's sum of the forward partials: every workgroup needs it, and a single thread walking the up to 480 partials one dependent load at a
     // time made this pass 6x its traffic time (61 us at 192x640); all 256 threads take a strided share, in the same fixed order in every workgroup
@@ -839,8 +847,8 @@ __global__ void __launch_bounds__(256) smooth_bwd_kernel(const float* __restrict
         sh[1] = s;
     }
     __syncthreads();
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = bx * 64 + (threadIdx.x & 63);
+    const int y = by * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const float m = sh[0], S = sh[1];
     const long p = b * hw + (long)y * w + x;
@@ -851,6 +859,78 @@ __global__ void __launch_bounds__(256) smooth_bwd_kernel(const float* __restrict
     else dinv = dn[p] / 1e-6f;                                    // clamp active: mean treated as constant
     const float dd = (dv > 1e-6f) ? -dinv / (dv * dv) : 0.f;       // inv = 1 / clamp(depth, 1e-6)
     d_depth[p] = accumulate ? d_depth[p] + g * dd : g * dd;
+}
+
+__global__ void __launch_bounds__(256) smooth_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ dn, const float* __restrict__ mean_part,
+                                                         const float* __restrict__ s_part, int blocks_per_sample, const float* __restrict__ gout, float gscale,
+                                                         int h, int w, float* __restrict__ d_depth, int accumulate) {
+    smooth_bwd_body(depth, dn, mean_part, s_part, blocks_per_sample, gout, gscale, h, w, d_depth, accumulate, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Every scale of MonoDepth2's loss loop (MonoDepth2.py:L78-126) behind one launch per pass: the smoothness kernels over a linear grid whose block ranges
+// belong to the scales (each scale keeps the block partition of its single-scale launch, so every partial sum is the one that launch writes), and ONE
+// finalize for the photometric and the smoothness partial slabs that also forms the two weighted totals the reference accumulates scale by scale.
+struct SmoothArgs { const float* depth; const float* img; float* mean_part; float* dn; float* loss_part; float* s_part; const float* gout; float* d_depth; float gscale; int h, w; };
+struct SmoothMulti {
+    SmoothArgs a[PH_MAX_SCALES];
+    int first[PH_MAX_SCALES + 1];
+    int gdx[PH_MAX_SCALES], gdy[PH_MAX_SCALES];
+    int n, B, accumulate;
+};
+
+__global__ void __launch_bounds__(256) smooth_mean_multi_kernel(const SmoothMulti m) {
+    const SmoothArgs& a = m.a[blockIdx.z];
+    smooth_mean_body(a.depth, a.h * a.w, a.mean_part, blockIdx.y, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) smooth_fwd_multi_kernel(const SmoothMulti m) {
+    int s = 0;
+    while (s + 1 < m.n && (int)blockIdx.x >= m.first[s + 1]) ++s;
+    const int local = blockIdx.x - m.first[s], gdx = m.gdx[s], gdy = m.gdy[s];
+    const SmoothArgs& a = m.a[s];
+    smooth_fwd_body(a.depth, a.img, a.mean_part, m.B, a.h, a.w, a.dn, a.loss_part, a.s_part, local % gdx, (local / gdx) % gdy, local / (gdx * gdy), gdx, gdy);
+}
+
+__global__ void __launch_bounds__(256) smooth_bwd_multi_kernel(const SmoothMulti m) {
+    int s = 0;
+    while (s + 1 < m.n && (int)blockIdx.x >= m.first[s + 1]) ++s;
+    const int local = blockIdx.x - m.first[s], gdx = m.gdx[s], gdy = m.gdy[s];
+    const SmoothArgs& a = m.a[s];
+    smooth_bwd_body(a.depth, a.dn, a.mean_part, a.s_part, gdx * gdy, a.gout, a.gscale, a.h, a.w, a.d_depth, m.accumulate, local % gdx, (local / gdx) % gdy, local / (gdx * gdy));
+}
+
+// One workgroup per partial slab (photometric scales first, then smoothness scales): per_scale[k] = scale[k] * sum(slab k) in the fixed order of
+// reduce_partials_kernel; the workgroup that finishes last (device-scope ticket, left at zero again) adds up totals[0] = sum_k<nphoto weight[k] * per_scale[k] and
+// totals[1] = the same over the smoothness slabs, in scale order -- the order of the reference's `loss += term * w` (MonoDepth2.py:L103-112, L126).
+struct MonoReduce {
+    const float* partial[2 * PH_MAX_SCALES];
+    int n[2 * PH_MAX_SCALES];
+    float scale[2 * PH_MAX_SCALES], weight[2 * PH_MAX_SCALES];
+    int count, nphoto;
+};
+__global__ void __launch_bounds__(256) mono_loss_finalize_kernel(const MonoReduce r, float* __restrict__ per_scale, float* __restrict__ totals, int* __restrict__ ticket) {
+    __shared__ float red[16];
+    __shared__ int last;
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < r.n[k]; i += 256) s += r.partial[k][i];
+    s = sde_block_sum(s, red);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(per_scale + k, s * r.scale[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == r.count - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        float t0 = 0.f, t1 = 0.f;
+        for (int j = 0; j < r.count; ++j) {
+            const float v = __hip_atomic_load(per_scale + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * r.weight[j];
+            if (j < r.nphoto) t0 += v; else t1 += v;
+        }
+        totals[0] = t0; totals[1] = t1;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1190,11 +1270,9 @@ static int fill_fwd_args(const sde_photo_desc* d, float* const* sampled, uint8_t
     return SDE_OK;
 }
 
-int sde_photo_multi_fwd(const sde_photo_desc* d, int n, float* const* sampled, uint8_t* const* sel, float* const* partial, float* loss_out,
-                        sde_stream_t stream) {
-    SDE_CHECK_ARG(d && sampled && sel && partial && loss_out && n >= 1 && n <= PH_MAX_SCALES, "sde_photo_multi_fwd: bad argument (n=%d)", n);
+static int photo_multi_fwd_launch(const sde_photo_desc* d, int n, float* const* sampled, uint8_t* const* sel, float* const* partial, hipStream_t st, MultiReduce& r) {
+    SDE_CHECK_ARG(d && sampled && sel && partial && n >= 1 && n <= PH_MAX_SCALES, "sde_photo_multi_fwd: bad argument (n=%d)", n);
     PhotoMulti m;
-    MultiReduce r;
     m.n = n; m.first[0] = 0;
     for (int s = 0; s < n; ++s) {
         SDE_CHECK_ARG(d[s].nctx == d[0].nctx && d[s].B == d[0].B && d[s].nctx >= 1 && d[s].nctx <= SDE_MAX_CTX && !d[s].clip_thr && d[s].B > 0 && d[s].h >= 4 && d[s].w >= 4,
@@ -1208,7 +1286,6 @@ int sde_photo_multi_fwd(const sde_photo_desc* d, int n, float* const* sampled, u
     for (int s = n; s < PH_MAX_SCALES; ++s) { m.gdx[s] = m.gdy[s] = 1; m.first[s + 1] = m.first[n]; r.partial[s] = nullptr; r.n[s] = 0; r.scale[s] = 0.f; m.a[s] = m.a[0]; }
     const dim3 grid(m.first[n]), blk(FT_W, FT_H);
     const size_t lds = photo_fwd_lds(d[0].nctx);
-    hipStream_t st = (hipStream_t)stream;
     switch (d[0].nctx) {
         case 1: hipLaunchKernelGGL(photo_fwd_multi_kernel<1>, grid, blk, lds, st, m); break;
         case 2: hipLaunchKernelGGL(photo_fwd_multi_kernel<2>, grid, blk, lds, st, m); break;
@@ -1216,13 +1293,24 @@ int sde_photo_multi_fwd(const sde_photo_desc* d, int n, float* const* sampled, u
         default: hipLaunchKernelGGL(photo_fwd_multi_kernel<4>, grid, blk, lds, st, m); break;
     }
     SDE_CHECK_LAUNCH("sde_photo_multi_fwd");
+    return SDE_OK;
+}
+
+int sde_photo_multi_fwd(const sde_photo_desc* d, int n, float* const* sampled, uint8_t* const* sel, float* const* partial, float* loss_out,
+                        sde_stream_t stream) {
+    SDE_CHECK_ARG(loss_out, "sde_photo_multi_fwd: null loss_out");
+    MultiReduce r;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = photo_multi_fwd_launch(d, n, sampled, sel, partial, st, r);
+    if (rc) return rc;
     hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(n), dim3(256), 0, st, r, loss_out);
     SDE_CHECK_LAUNCH("sde_photo_multi_fwd/reduce");
     return SDE_OK;
 }
 
-int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* sampled, const uint8_t* const* sel, const float* gout, float* const* d_depth,
-                        float* const* pose_partial, float* const* d_pose, sde_stream_t stream) {
+// gout + s * gout_stride is scale s's upstream gradient (a device scalar); weight (host, may be null) scales it further
+static int photo_multi_bwd_launch(const sde_photo_desc* d, int n, const float* const* sampled, const uint8_t* const* sel, const float* gout, int gout_stride,
+                                  const float* weight, float* const* d_depth, float* const* pose_partial, float* const* d_pose, hipStream_t st) {
     // d_pose == NULL: the pose partials are left for sde_photo_multi_pose_finalize (which the caller may enqueue on another stream)
     SDE_CHECK_ARG(d && sampled && sel && gout && d_depth && pose_partial && n >= 1 && n <= PH_MAX_SCALES, "sde_photo_multi_bwd: bad argument (n=%d)", n);
     PhotoBwdMulti m;
@@ -1233,7 +1321,7 @@ int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* samp
         SDE_CHECK_ARG(ds.nctx == d[0].nctx && ds.B == d[0].B && ds.nctx >= 1 && ds.nctx <= SDE_MAX_CTX && !ds.clip_thr && ds.A && ds.depth && ds.K && d_depth[s] && pose_partial[s] &&
                       (ds.reduce_mean || sel[s]), "sde_photo_multi_bwd: scale %d: bad descriptor", s);
         PhotoBwdArgs& a = m.a[s];
-        a.A = ds.A; a.depth = ds.depth; a.K = ds.K; a.sel = sel[s]; a.gout = gout + s; a.d_depth = d_depth[s]; a.pose_partial = pose_partial[s];
+        a.A = ds.A; a.depth = ds.depth; a.K = ds.K; a.sel = sel[s]; a.gout = gout + s * gout_stride; a.d_depth = d_depth[s]; a.pose_partial = pose_partial[s];
         for (int j = 0; j < SDE_MAX_CTX; ++j) {
             a.ctx[j] = j < ds.nctx ? ds.ctx[j] : nullptr;
             a.pose[j] = j < ds.nctx ? ds.pose[j] : nullptr;
@@ -1242,14 +1330,13 @@ int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* samp
         }
         a.B = ds.B; a.h = ds.h; a.w = ds.w; a.nctx = ds.nctx; a.automask = ds.automask; a.reduce_mean = ds.reduce_mean; a.accumulate = 0; a.clip = 0;
         a.sx = ds.sx; a.sy = ds.sy; a.ssim_w = ds.ssim_w; a.C1 = ds.C1; a.C2 = ds.C2;
-        a.gscale = 1.0f / ((float)ds.B * ds.h * ds.w);
+        a.gscale = (weight ? weight[s] : 1.0f) / ((float)ds.B * ds.h * ds.w);
         m.gdx[s] = sde_cdiv(ds.w, BT_W - 4); m.gdy[s] = sde_cdiv(ds.h, BT_H - 4);
         m.first[s + 1] = m.first[s] + m.gdx[s] * m.gdy[s] * ds.B;
         mp.partial[s] = pose_partial[s]; mp.blocks_per_sample[s] = m.gdx[s] * m.gdy[s];
     }
     for (int s = n; s < PH_MAX_SCALES; ++s) { m.gdx[s] = m.gdy[s] = 1; m.first[s + 1] = m.first[n]; m.a[s] = m.a[0]; mp.partial[s] = nullptr; mp.blocks_per_sample[s] = 0; }
     const dim3 grid(m.first[n]), blk(BT_W, BT_H);
-    hipStream_t st = (hipStream_t)stream;
     const size_t lds = photo_bwd_lds();
     switch (d[0].nctx) {
         case 1: hipLaunchKernelGGL((photo_bwd_multi_kernel<1, false>), grid, blk, lds, st, m); break;
@@ -1265,6 +1352,86 @@ int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* samp
     hipLaunchKernelGGL(pose_grad_finalize_multi_kernel, dim3(d[0].B, d[0].nctx), dim3(64), 0, st, mp, d[0].nctx, d[0].B, d_pose[0], d[0].nctx > 1 ? d_pose[1] : nullptr,
                        d[0].nctx > 2 ? d_pose[2] : nullptr, d[0].nctx > 3 ? d_pose[3] : nullptr);
     SDE_CHECK_LAUNCH("sde_photo_multi_bwd/finalize");
+    return SDE_OK;
+}
+
+int sde_photo_multi_bwd(const sde_photo_desc* d, int n, const float* const* sampled, const uint8_t* const* sel, const float* gout, float* const* d_depth,
+                        float* const* pose_partial, float* const* d_pose, sde_stream_t stream) {
+    return photo_multi_bwd_launch(d, n, sampled, sel, gout, 1, nullptr, d_depth, pose_partial, d_pose, (hipStream_t)stream);
+}
+
+// ---- photometric + smoothness terms of every scale (MonoDepth2.py:L78-126) ----
+static int smooth_multi_fill(const sde_photo_desc* d, int n, SmoothMulti& m, const char* who) {
+    m.n = n; m.B = d[0].B; m.first[0] = 0; m.accumulate = 0;
+    for (int s = 0; s < n; ++s) {
+        SDE_CHECK_ARG(d[s].depth && d[s].A && d[s].B == d[0].B && d[s].B > 0 && d[s].h > 1 && d[s].w > 1, "%s: scale %d: bad descriptor", who, s);
+        SmoothArgs& a = m.a[s];
+        a = SmoothArgs{};
+        a.depth = d[s].depth; a.img = d[s].A; a.h = d[s].h; a.w = d[s].w;
+        m.gdx[s] = sde_cdiv(d[s].w, 64); m.gdy[s] = sde_cdiv(d[s].h, 4);
+        m.first[s + 1] = m.first[s] + m.gdx[s] * m.gdy[s] * d[s].B;
+    }
+    for (int s = n; s < PH_MAX_SCALES; ++s) { m.a[s] = m.a[0]; m.gdx[s] = m.gdy[s] = 1; m.first[s + 1] = m.first[n]; }
+    return SDE_OK;
+}
+
+int sde_mono_loss_fwd(const sde_photo_desc* d, int n, const float* photo_w, const float* smooth_w, float* const* sampled, uint8_t* const* sel,
+                      float* const* photo_partial, float* const* sm_mean_part, float* const* sm_dn, float* const* sm_loss_part, float* const* sm_s_part,
+                      float* per_scale, float* totals, int* ticket, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && photo_w && per_scale && totals && ticket && n >= 1 && n <= PH_MAX_SCALES, "sde_mono_loss_fwd: bad argument (n=%d)", n);
+    SDE_CHECK_ARG(!smooth_w || (sm_mean_part && sm_dn && sm_loss_part && sm_s_part), "sde_mono_loss_fwd: smoothness weights without smoothness buffers");
+    hipStream_t st = (hipStream_t)stream;
+    MonoReduce mr;
+    mr.nphoto = n; mr.count = smooth_w ? 2 * n : n;
+    for (int k = 0; k < 2 * PH_MAX_SCALES; ++k) { mr.partial[k] = nullptr; mr.n[k] = 0; mr.scale[k] = mr.weight[k] = 0.f; }
+    if (smooth_w) {
+        SmoothMulti m;
+        int rc = smooth_multi_fill(d, n, m, "sde_mono_loss_fwd");
+        if (rc) return rc;
+        for (int s = 0; s < n; ++s) {
+            SDE_CHECK_ARG(sm_mean_part[s] && sm_dn[s] && sm_loss_part[s] && sm_s_part[s], "sde_mono_loss_fwd: scale %d: null smoothness buffer", s);
+            m.a[s].mean_part = sm_mean_part[s]; m.a[s].dn = sm_dn[s]; m.a[s].loss_part = sm_loss_part[s]; m.a[s].s_part = sm_s_part[s];
+            mr.partial[n + s] = sm_loss_part[s]; mr.n[n + s] = m.first[s + 1] - m.first[s]; mr.scale[n + s] = 1.0f; mr.weight[n + s] = smooth_w[s];
+        }
+        hipLaunchKernelGGL(smooth_mean_multi_kernel, dim3(SM_CHUNKS, d[0].B, n), dim3(256), 0, st, m);
+        SDE_CHECK_LAUNCH("sde_mono_loss_fwd/mean");
+        hipLaunchKernelGGL(smooth_fwd_multi_kernel, dim3(m.first[n]), dim3(256), 0, st, m);
+        SDE_CHECK_LAUNCH("sde_mono_loss_fwd/smooth");
+    }
+    MultiReduce r;
+    const int rc = photo_multi_fwd_launch(d, n, sampled, sel, photo_partial, st, r);
+    if (rc) return rc;
+    for (int s = 0; s < n; ++s) { mr.partial[s] = r.partial[s]; mr.n[s] = r.n[s]; mr.scale[s] = r.scale[s]; mr.weight[s] = photo_w[s]; }
+    hipLaunchKernelGGL(mono_loss_finalize_kernel, dim3(mr.count), dim3(256), 0, st, mr, per_scale, totals, ticket);
+    SDE_CHECK_LAUNCH("sde_mono_loss_fwd/finalize");
+    return SDE_OK;
+}
+
+int sde_mono_loss_bwd(const sde_photo_desc* d, int n, const float* photo_w, const float* smooth_w, const float* const* sampled, const uint8_t* const* sel,
+                      const float* g_rec, const float* g_smooth, const float* const* sm_mean_part, const float* const* sm_dn, const float* const* sm_s_part,
+                      float* const* d_depth, float* const* pose_partial, float* const* d_pose, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && photo_w && g_rec && d_depth && n >= 1 && n <= PH_MAX_SCALES, "sde_mono_loss_bwd: bad argument (n=%d)", n);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = photo_multi_bwd_launch(d, n, sampled, sel, g_rec, 0, photo_w, d_depth, pose_partial, d_pose, st);      // writes d_depth
+    if (rc) return rc;
+    if (smooth_w && g_smooth) return sde_smooth_multi_bwd(d, n, smooth_w, g_smooth, sm_mean_part, sm_dn, sm_s_part, d_depth, 1, stream);      // ... the smoothness term adds to it
+    return SDE_OK;
+}
+
+int sde_smooth_multi_bwd(const sde_photo_desc* d, int n, const float* smooth_w, const float* g_smooth, const float* const* sm_mean_part, const float* const* sm_dn,
+                         const float* const* sm_s_part, float* const* d_depth, int accumulate, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && smooth_w && g_smooth && sm_mean_part && sm_dn && sm_s_part && d_depth && n >= 1 && n <= PH_MAX_SCALES, "sde_smooth_multi_bwd: bad argument (n=%d)", n);
+    SmoothMulti m;
+    const int rc = smooth_multi_fill(d, n, m, "sde_smooth_multi_bwd");
+    if (rc) return rc;
+    m.accumulate = accumulate ? 1 : 0;
+    for (int s = 0; s < n; ++s) {
+        SDE_CHECK_ARG(sm_mean_part[s] && sm_dn[s] && sm_s_part[s] && d_depth[s], "sde_smooth_multi_bwd: scale %d: null buffer", s);
+        m.a[s].mean_part = (float*)sm_mean_part[s]; m.a[s].dn = (float*)sm_dn[s]; m.a[s].s_part = (float*)sm_s_part[s];
+        m.a[s].gout = g_smooth; m.a[s].gscale = smooth_w[s]; m.a[s].d_depth = d_depth[s];
+    }
+    hipLaunchKernelGGL(smooth_bwd_multi_kernel, dim3(m.first[n]), dim3(256), 0, (hipStream_t)stream, m);
+    SDE_CHECK_LAUNCH("sde_smooth_multi_bwd");
     return SDE_OK;
 }
 

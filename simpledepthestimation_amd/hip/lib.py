@@ -39,6 +39,9 @@ _PROTOS = {
     "sde_photo_multi_fwd": ([_P, _I, _P, _P, _P, _P, _P], c_int),
     "sde_photo_multi_bwd": ([_P, _I, _P, _P, _P, _P, _P, _P, _P], c_int),
     "sde_photo_multi_pose_finalize": ([_P, _I, _P, _P, _P], c_int),
+    "sde_mono_loss_fwd": ([_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
+    "sde_mono_loss_bwd": ([_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], c_int),
+    "sde_smooth_multi_bwd": ([_P, _I, _P, _P, _P, _P, _P, _P, _I, _P], c_int),
     "sde_ssim_fwd": ([_P, _P, _I, _I, _I, _I, _F, _F, _P, _P], c_int),
     "sde_ssim_bwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P], c_int),
     "sde_smooth_num_blocks": ([_I, _I, _I], c_int),

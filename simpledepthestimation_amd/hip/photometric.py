@@ -248,6 +248,142 @@ def photometric_multi_loss(depths, K, As, ctxs_per_scale, poses, scales, ssim_w=
                              pose_stream, *depths, *As, *flat_ctx, *poses)
 
 
+_TICKET = {}
+
+
+def _ticket(dev):
+    """The finalize kernel's arrival counter: one device int per device, zero between launches (the kernel resets it)."""
+    if dev not in _TICKET:
+        _TICKET[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _TICKET[dev]
+
+
+class _MonoLoss(torch.autograd.Function):
+    """Photometric + smoothness terms of every scale (MonoDepth2.py:L78-126): (rec_loss, smooth_loss, per-scale values [2n]) in four launches forward and
+    two backward; the depth gradient of a scale is written once (photometric) and accumulated once (smoothness) instead of being summed by autograd."""
+
+    @staticmethod
+    def forward(ctx, K, ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales, photo_w, smooth_w, pose_stream, *rest):
+        depths, As = rest[:n], rest[n:2 * n]
+        ctxs = rest[2 * n:2 * n + n * nctx]               # scale-major
+        poses = rest[2 * n + n * nctx:]
+        K = _f32c(K)
+        depths = [_f32c(d) for d in depths]; As = [_f32c(a) for a in As]
+        ctxs = [_f32c(c) for c in ctxs]; poses = [_f32c(p) for p in poses]
+        dev = K.device
+        lib = L.lib()
+        B = depths[0].shape[0]
+        descs = (L.PhotoDesc * n)()
+        sampled, sels, partials, sm = [], [], [], []
+        samp_arr = (ctypes.c_void_p * (n * L.MAX_CTX))()
+        arr = lambda: (ctypes.c_void_p * n)()
+        sel_arr, part_arr, mean_arr, dn_arr, lp_arr, sp_arr = arr(), arr(), arr(), arr(), arr(), arr()
+        for s in range(n):
+            _, _, h, w = depths[s].shape
+            sx, sy = scales[s]
+            d = _desc(As[s], ctxs[s * nctx:(s + 1) * nctx], poses, depths[s], K, sx, sy, ssim_w, C1, C2, automask, reduce_mean)
+            ctypes.memmove(ctypes.byref(descs, s * ctypes.sizeof(L.PhotoDesc)), ctypes.byref(d), ctypes.sizeof(L.PhotoDesc))
+            smp = [torch.empty(B, 3, h, w, device=dev) for _ in range(nctx)]
+            for j, t in enumerate(smp):
+                samp_arr[s * L.MAX_CTX + j] = t.data_ptr()
+            sampled += smp
+            sels.append(torch.empty(B, h, w, device=dev, dtype=torch.uint8)); sel_arr[s] = sels[-1].data_ptr()
+            partials.append(torch.empty(lib.sde_photo_num_blocks(B, h, w, 0), device=dev)); part_arr[s] = partials[-1].data_ptr()
+            if smooth_w is not None:
+                nb = lib.sde_smooth_num_blocks(B, h, w)
+                mean_part, dn, loss_part, s_part = torch.empty(B * 32, device=dev), torch.empty(B, h, w, device=dev), torch.empty(nb, device=dev), torch.empty(nb, device=dev)
+                sm += [mean_part, dn, s_part]
+                mean_arr[s], dn_arr[s], lp_arr[s], sp_arr[s] = mean_part.data_ptr(), dn.data_ptr(), loss_part.data_ptr(), s_part.data_ptr()
+                partials.append(loss_part)
+        per_scale = torch.empty(2 * n, device=dev)
+        totals = torch.empty(2, device=dev)
+        pw = (ctypes.c_float * n)(*photo_w)
+        sw = (ctypes.c_float * n)(*smooth_w) if smooth_w is not None else None
+        h0, w0 = depths[0].shape[-2:]
+        nbytes = sum(B * d.shape[-2] * d.shape[-1] * (16 + 12 * nctx) for d in depths)
+        L.timed("photo_fwd", nbytes, nctx, lambda: L.check(lib.sde_mono_loss_fwd(descs, n, pw, sw, samp_arr, sel_arr, part_arr, mean_arr, dn_arr, lp_arr, sp_arr,
+                                                                                 L.ptr(per_scale), L.ptr(totals), L.ptr(_ticket(dev)), L.stream()), "sde_mono_loss_fwd"),
+                dict(B=B, h=h0, w=w0, scales=n))
+        ctx.save_for_backward(K, *depths, *As, *ctxs, *poses, *sampled, *sels, *sm)
+        ctx.cfg = (ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales, photo_w, smooth_w)
+        ctx.pose_stream = pose_stream
+        ctx.mark_non_differentiable(per_scale)
+        return totals[0], totals[1], per_scale
+
+    @staticmethod
+    def backward(ctx, g_rec, g_smooth, _g_per_scale):
+        ssim_w, C1, C2, automask, reduce_mean, n, nctx, scales, photo_w, smooth_w = ctx.cfg
+        t = ctx.saved_tensors
+        K = t[0]
+        o = 1
+        depths = t[o:o + n]; o += n
+        As = t[o:o + n]; o += n
+        ctxs = t[o:o + n * nctx]; o += n * nctx
+        poses = t[o:o + nctx]; o += nctx
+        sampled = t[o:o + n * nctx]; o += n * nctx
+        sels = t[o:o + n]; o += n
+        sm = t[o:]
+        dev = K.device
+        lib = L.lib()
+        B = depths[0].shape[0]
+        descs = (L.PhotoDesc * n)()
+        samp_arr = (ctypes.c_void_p * (n * L.MAX_CTX))()
+        arr = lambda: (ctypes.c_void_p * n)()
+        sel_arr, dd_arr, pp_arr, mean_arr, dn_arr, sp_arr = arr(), arr(), arr(), arr(), arr(), arr()
+        d_depths, pps = [], []
+        for s in range(n):
+            _, _, h, w = depths[s].shape
+            sx, sy = scales[s]
+            d = _desc(As[s], ctxs[s * nctx:(s + 1) * nctx], poses, depths[s], K, sx, sy, ssim_w, C1, C2, automask, reduce_mean)
+            ctypes.memmove(ctypes.byref(descs, s * ctypes.sizeof(L.PhotoDesc)), ctypes.byref(d), ctypes.sizeof(L.PhotoDesc))
+            for j in range(nctx):
+                samp_arr[s * L.MAX_CTX + j] = sampled[s * nctx + j].data_ptr()
+            sel_arr[s] = sels[s].data_ptr()
+            d_depths.append(torch.empty_like(depths[s])); dd_arr[s] = d_depths[-1].data_ptr()
+            pps.append(torch.empty(lib.sde_photo_num_blocks(B, h, w, 1) * nctx * 12, device=dev)); pp_arr[s] = pps[-1].data_ptr()
+            if smooth_w is not None:
+                mean_arr[s], dn_arr[s], sp_arr[s] = sm[3 * s].data_ptr(), sm[3 * s + 1].data_ptr(), sm[3 * s + 2].data_ptr()
+        d_pose = [torch.empty(B, 4, 4, device=dev) for _ in range(nctx)]
+        if g_rec is None:                       # rec_loss not part of the objective: its gradient is zero
+            g_rec = torch.zeros((), device=dev)
+        g_rec = _f32c(g_rec)
+        g_smooth = _f32c(g_smooth) if (g_smooth is not None and smooth_w is not None) else None
+        pw = (ctypes.c_float * n)(*photo_w)
+        sw = (ctypes.c_float * n)(*smooth_w) if smooth_w is not None else None
+        h0, w0 = depths[0].shape[-2:]
+        nbytes = sum(B * d.shape[-2] * d.shape[-1] * (21 + 24 * nctx) for d in depths)
+        # the pose side goes to PoseNet's stream, enqueued before the main stream's next kernel (see _PhotoMulti.backward)
+        aux = ctx.pose_stream if L.PROFILE is None else None
+        L.timed("photo_bwd", nbytes, nctx, lambda: L.check(lib.sde_mono_loss_bwd(descs, n, pw, None, samp_arr, sel_arr, L.ptr(g_rec), None, None, None, None, dd_arr, pp_arr,
+                                                                                 None if aux is not None else L.ptr_array(d_pose), L.stream()), "sde_mono_loss_bwd"),
+                dict(B=B, h=h0, w=w0, scales=n))
+        if aux is not None:
+            aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux):
+                L.check(lib.sde_photo_multi_pose_finalize(descs, n, pp_arr, L.ptr_array(d_pose), L.stream()), "sde_photo_multi_pose_finalize")
+            for t_ in pps + d_pose:
+                t_.record_stream(aux)
+        if g_smooth is not None:
+            L.check(lib.sde_smooth_multi_bwd(descs, n, sw, L.ptr(g_smooth), mean_arr, dn_arr, sp_arr, dd_arr, 1, L.stream()), "sde_smooth_multi_bwd")
+        return (None,) * 12 + tuple(d_depths) + (None,) * n + (None,) * (n * nctx) + tuple(d_pose)
+
+
+def mono_loss(depths, K, As, ctxs_per_scale, poses, scales, photo_w, smooth_w=None, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min", pose_stream=None):
+    """MonoDepth2's loss loop over the scales (MonoDepth2.py:L78-126), photometric and smoothness terms: returns (rec_loss, smooth_loss, per_scale) with
+    rec_loss = sum_s photo_w[s] * photometric_scale_loss(scale s), smooth_loss = sum_s smooth_w[s] * smoothness_loss(scale s) (zero without smooth_w) and
+    per_scale [2n] the unweighted terms (no gradient).  Arguments as for photometric_multi_loss."""
+    if reduce not in ("min", "mean"):
+        raise NotImplementedError(reduce)
+    n, nctx = len(depths), len(poses)
+    if not (1 <= n <= PH_MAX_SCALES and len(As) == n and len(ctxs_per_scale) == n and all(len(c) == nctx for c in ctxs_per_scale) and len(photo_w) == n
+            and (smooth_w is None or len(smooth_w) == n)):
+        raise L.SdeHipError("mono_loss: 1-4 scales, one target, nctx context frames and one weight per scale")
+    flat_ctx = [c for cs in ctxs_per_scale for c in cs]
+    return _MonoLoss.apply(K, float(ssim_w), float(C1), float(C2), bool(automask), reduce == "mean", n, nctx, tuple((float(a), float(b)) for a, b in scales),
+                           tuple(float(v) for v in photo_w), None if smooth_w is None else tuple(float(v) for v in smooth_w), pose_stream,
+                           *depths, *As, *flat_ctx, *poses)
+
+
 def photometric_maps(depth, K, A, ctxs, poses, sx, sy, ssim_w=0.85, C1=1e-4, C2=9e-4, automask=True, reduce="min"):
     """Forward only, exposing the individual maps / sampled frames / arg-min (tests, debugging)."""
     depth, K, A = _f32c(depth), _f32c(K), _f32c(A)

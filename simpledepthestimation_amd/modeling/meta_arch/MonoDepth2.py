@@ -16,9 +16,11 @@ from .build import META_ARCH_REGISTRY
 from .common import HipMetaArch
 
 
-# Every scale of the photometric loss in one launch per phase (sde_photo_multi_fwd / _bwd; bench.py --opt photo_multi=1).  Kernel time: forward 116 us against
-# 90 + 31 + 19 + 14, backward 187 against 148 + 50 + 22 + 17 (192x640, bs 12) -- but the replayed step measured SLOWER with it in two A/B pairs of one call
-# (MonoDepth2-R18 4.45 / 4.46 against 4.36 / 4.32 ms, R50 7.85 / 7.81 against 7.69 / 7.67), so the per-scale launches stay the default.
+# Every scale of the photometric and the smoothness term in one launch per phase (sde_mono_loss_fwd / _bwd; bench.py --opt photo_multi=0 selects the
+# per-scale path).  Kernel time: photometric forward 116 us against 90 + 31 + 19 + 14, backward 187 against 148 + 50 + 22 + 17 (192x640, bs 12), and ~30 fewer
+# launch-sized kernels on the serial seam between the two passes.  With the pose-gradient sum enqueued on PoseNet's stream first (hip/photometric.py) the
+# replayed step is faster too: MonoDepth2-R18 4.33 -> 4.15 ms, R50 7.69 -> 7.48 (photometric launches alone; before that change the runtime's queue
+# assignment put PoseNet's backward behind the depth network's and the step was SLOWER, 4.46 / 7.83).
 MULTI_SCALE_PHOTO = True
 
 
@@ -82,7 +84,7 @@ class MonoDepth2Model(HipMetaArch):
             poses[0].register_hook(_marker("pose_bwd_start"))
         H, W = image.shape[-2:]
         terms = defaultdict(lambda: ([], []))        # loss name -> (per-scale 0-d tensors, their weights)
-        photo_losses, pyr = [], []
+        photo_losses, pyr, smooth_ws = [], [], []
         # every scale of the photometric loss in ONE launch per phase (sde_photo_multi_fwd / _bwd) unless LOSS.CLIP needs the per-scale statistics
         multi = MULTI_SCALE_PHOTO and not (self.clip_loss and self.clip_loss > 0.0) and 1 <= num_scales <= HP.PH_MAX_SCALES
         for i in range(num_scales):
@@ -101,7 +103,10 @@ class MonoDepth2Model(HipMetaArch):
             def add(name, value, weight):
                 terms[name][0].append(value); terms[name][1].append(weight)
             if self.smooth_loss_w > 0.0:
-                add("smooth_loss", smoothness_loss(depth_pred[i], resized_image), scale_w * self.smooth_loss_w / num_scales)
+                if multi:
+                    smooth_ws.append(scale_w * self.smooth_loss_w / num_scales)       # the term itself rides in the all-scales launches below
+                else:
+                    add("smooth_loss", smoothness_loss(depth_pred[i], resized_image), scale_w * self.smooth_loss_w / num_scales)
             if self.sup_loss_w > 0.0:
                 # the reference weights this term with smooth_loss_w (MonoDepth2.py:L109, sic)
                 add("sup_loss", self.supervise_loss(depth_pred[i], batch["depth"]), scale_w * self.smooth_loss_w / num_scales)
@@ -110,10 +115,15 @@ class MonoDepth2Model(HipMetaArch):
         # the reference accumulates `loss += term_i * w_i` scale by scale (MonoDepth2.py:L103-112, L126): per loss that is 2 tiny kernels per scale forward
         # and as many backward; one stack + one dot product with a cached weight vector is the same sum (fp32, 4 terms) in 2 + 1 kernels
         if multi:
-            photo_losses = HP.photometric_multi_loss(depth_pred, intrinsics, [p[0] for p in pyr], [p[1] for p in pyr], poses, [(p[2], p[3]) for p in pyr],
-                                                     ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2, automask=self.use_automask,
-                                                     reduce=self.photometric_reduce, pose_stream=pose_stream)
-        output["rec_loss"] = self._weighted_sum(photo_losses, [1.0 / num_scales] * num_scales)
+            # photometric + smoothness terms of all scales, weighted and summed, in four launches forward and two backward (sde_mono_loss_fwd / _bwd)
+            rec, smooth, _ = HP.mono_loss(depth_pred, intrinsics, [p[0] for p in pyr], [p[1] for p in pyr], poses, [(p[2], p[3]) for p in pyr],
+                                          [1.0 / num_scales] * num_scales, smooth_ws or None, ssim_w=self.ssim_loss_weight, C1=self.ssim.C1, C2=self.ssim.C2,
+                                          automask=self.use_automask, reduce=self.photometric_reduce, pose_stream=pose_stream)
+            output["rec_loss"] = rec
+            if smooth_ws:
+                output["smooth_loss"] = smooth
+        else:
+            output["rec_loss"] = self._weighted_sum(photo_losses, [1.0 / num_scales] * num_scales)
         for name, (vals, ws) in terms.items():
             output[name] = self._weighted_sum(vals, ws)
         return output
