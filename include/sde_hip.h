@@ -44,6 +44,9 @@ int sde_version(void);            /* ABI version, bumped on incompatible change 
  * hipGraph at chosen points, the markers give the replayed step's real timeline (bench.py --marks).  Not part of the reference's surface. */
 int sde_mark_time(uint64_t* slot, sde_stream_t stream);
 int sde_wall_clock_khz(void); /* < 0: query failed */
+/* Stream-ordered flag for the host: *dst = value (dst: host-pinned, device-visible memory; system-scope release store by one thread).  The device
+ * prefetcher's hand-over between its copy stream and the training stream (no event record / wait pairs). */
+int sde_store_u64(uint64_t* dst, uint64_t value, sde_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Geometry / photometric path (fp32)

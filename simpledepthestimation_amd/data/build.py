@@ -6,6 +6,8 @@ at a time.  ``DevicePrefetcher`` is the MI355X-side addition: batches are staged
 while the previous step's hipGraph replays, so the step never waits on PCIe (35-106 MB of fp32 images per step)."""
 import logging
 
+import ctypes
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -129,16 +131,28 @@ def build_detection_test_loader(cfg):
     return data.DataLoader(dataset, num_workers=cfg.DATALOADER.NUM_WORKERS, batch_sampler=batch_sampler, collate_fn=dataset.batch_collator)
 
 
+def _mark(name):
+    """Timeline marker on the current stream when a diagnostic run switched them on (hip.lib.marks_enable); a no-op otherwise."""
+    from ..hip import lib as L
+    if L.MARKS is not None:
+        L.mark(name)
+
+
 class DevicePrefetcher:
-    """Wraps a loader: batch k+1 is copied host -> device on a copy stream while step k runs; __next__ makes the consumer's stream wait on the copy's
-    event (no host synchronisation).  Arrays (tensors, numpy arrays, lists of them) move; everything else (flip, metadata) passes through.  len() and
-    re-iteration follow the wrapped loader.
+    """Wraps a loader: the next `ahead` batches are copied host -> device on a copy stream while step k runs.  Arrays (tensors, numpy arrays, lists of
+    them) move; everything else (flip, metadata) passes through.  len() and re-iteration follow the wrapped loader.
 
     The device side is a ring of `slots` persistent buffer sets (static shapes: what the captured hipGraph needs, too): entry `k` of a batch lands in
     the same device tensor every `slots` batches, so the steady state allocates nothing -- per-step allocations on a side stream make the caching
     allocator wait for (or hipMalloc around) blocks the main stream still uses, and the host ends up pacing the GPU (measured: 7.6 ms of host time
-    per 6.6 ms step).  A slot is rewritten only behind the event the consumer's stream recorded when it came back for the NEXT batch, i.e. after
-    everything it enqueued on that slot's tensors -- which is why a yielded batch is valid until the iterator is advanced `slots - 1` more times.
+    per 6.6 ms step).
+
+    Hand-over without events: a one-thread kernel behind the uploads stores the batch's sequence number into pinned host memory (sde_store_u64), the
+    host hands the batch over once it has SEEN that number (two batches ahead it normally has), and the consumer's stream needs no cross-stream wait;
+    the other way round, a flag store enqueued on the consumer's stream when it comes back for the next batch tells the host that the slot may be
+    rewritten.  The hipEventRecord / hipStreamWaitEvent pairs this replaces left the GPU idle for 0.5 ms per step between two replays of the step
+    graph (MonoDepth2-R18: 4.68 ms/step with events, 4.07 with resident inputs; in-graph markers and a variant probe in profiles/README.md, round 3).
+    A yielded batch is valid until the iterator is advanced `slots - ahead` more times.
     device_aug: optional callable(batch, buffers) run on the copy stream right behind the uploads (data/device_aug.py: DeviceImageAug turns the raw
     uint8 frames of the ON_DEVICE preprocess chain into the fp32 image entries).  Without it the raw entries are uploaded like any other array and
     the consumer transforms them -- HipTrainer.input_transform = DeviceImageAug(...) runs the kernels at the head of the step, straight into the
@@ -146,13 +160,20 @@ class DevicePrefetcher:
 
     _RAW = ("img_u8", "ctx_img_u8", "aug_params", "device_resize")     # consumed by device_aug (which uploads them itself)
 
-    def __init__(self, loader, device, device_aug=None, slots=3):
+    def __init__(self, loader, device, device_aug=None, slots=4, ahead=2):
         self.loader, self.device = loader, torch.device(device)
         self.device_aug = device_aug
         self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._slots = max(2, int(slots))
+        # batches staged ahead of the one being consumed.  Two, not one: HIP streams share a handful of hardware queues, and an upload that lands on
+        # the queue of one of the step graph's branches starts only when that branch has drained, i.e. at the END of the running step -- one batch
+        # ahead, the next step then began by waiting 0.5 ms for its frames (MonoDepth2-R18, in-graph markers); two ahead it has a whole step of slack
+        self._ahead = max(1, min(int(ahead), self._slots - 1))
+        # hand-over flags in pinned host memory, written in stream order by one-thread kernels (sde_store_u64) and polled by the host:
+        # _flags[0][slot] = sequence number of the last upload that COMPLETED into the slot, _flags[1][slot] = of the last batch the consumer is DONE with
+        self._flags = torch.zeros(2, self._slots, dtype=torch.int64).pin_memory() if self._stream is not None else None
+        self._seq = [0] * self._slots                         # per slot: sequence number (1-based batch count) of the batch staged into it last
         self._bufs = [dict() for _ in range(self._slots)]      # per slot: key -> persistent device tensor
-        self._release = [None] * self._slots                  # per slot: event on the consumer's stream behind its last use
 
     def __len__(self):
         return len(self.loader)
@@ -181,35 +202,52 @@ class DevicePrefetcher:
             out = {k: self._move(None, k, v) for k, v in batch.items()}
             return (self.device_aug(out) if self.device_aug is not None else out), None
         bufs = self._bufs[slot]
+        self._host_wait(1, slot, self._seq[slot])             # the consumer is done with the batch this slot held (normally long since)
+        seq = self._seq[slot] = self._staged_count = getattr(self, "_staged_count", 0) + 1
         with torch.cuda.stream(self._stream):
-            if self._release[slot] is not None:
-                self._stream.wait_event(self._release[slot])      # the consumer is done with this slot's tensors
+            _mark("upload_begin")
             out = {k: (v if (self.device_aug is not None and k in self._RAW) else self._move(bufs, k, v)) for k, v in batch.items()}
             if self.device_aug is not None:
                 out = self.device_aug(out, bufs)
-            ev = torch.cuda.Event()
-            ev.record(self._stream)
-        return out, ev
+            _mark("upload_end")
+            self._signal(0, slot, seq)
+        return out, seq
+
+    def _signal(self, which, slot, seq):
+        """Enqueue on the current stream: flags[which][slot] = seq once everything enqueued before has completed."""
+        from ..hip import lib as L
+        L.check(L.lib().sde_store_u64(ctypes.c_void_p(self._flags.data_ptr() + 8 * (which * self._slots + slot)), seq, L.stream()), "sde_store_u64")
+
+    def _host_wait(self, which, slot, seq):
+        """Spin until flags[which][slot] >= seq (pinned memory the device writes; no HIP call, nothing enqueued on any stream)."""
+        if seq <= 0:
+            return
+        f = self._flags[which]
+        while int(f[slot]) < seq:
+            pass
 
     def __iter__(self):
+        from collections import deque
         it = iter(self.loader)
-        nxt, n = None, 0
-        try:
-            nxt = self._stage(next(it), 0)
-        except StopIteration:
-            return
-        while nxt is not None:
-            cur, ev = nxt
+        staged, n_staged, n = deque(), 0, 0
+        def stage_more():
+            nonlocal n_staged, it
+            while it is not None and len(staged) < self._ahead:          # (+ the batch in use = at most `ahead + 1` <= slots buffer sets alive)
+                try:
+                    b = next(it)
+                except StopIteration:
+                    it = None
+                    return
+                staged.append(self._stage(b, n_staged % self._slots))
+                n_staged += 1
+        stage_more()
+        while staged:
+            cur, seq = staged.popleft()
             slot = n % self._slots
             n += 1
-            try:
-                nxt = self._stage(next(it), n % self._slots)
-            except StopIteration:
-                nxt = None
-            if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+            stage_more()                            # the uploads of the next `ahead` batches are in flight before this one is handed over
+            if seq is not None:
+                self._host_wait(0, slot, seq)       # the upload has completed (the host saw its flag): the consumer's stream needs no wait of its own
             yield cur
-            if ev is not None:                      # the consumer came back: everything it enqueued on this slot's tensors is behind this event
-                rel = torch.cuda.Event()
-                rel.record(torch.cuda.current_stream(self.device))
-                self._release[slot] = rel
+            if seq is not None:                     # the consumer came back: everything it enqueued on this slot's tensors is ahead of this flag store
+                self._signal(1, slot, seq)

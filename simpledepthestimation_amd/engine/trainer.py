@@ -464,7 +464,9 @@ class HipTrainer:
     def step(self, batch):
         """One optimisation step.  Returns {loss name: 0-d device tensor} (no host sync)."""
         if self.input_transform is not None:
+            L.mark("pre_transform")
             batch = self.input_transform(batch, None, self._static_batch if self.use_graph else None)
+            L.mark("post_transform")
         if self.use_graph:
             hit = self._graphs.get(self._graph_key(batch)) if self._static_batch is not None else None
             if hit is None:
@@ -473,6 +475,7 @@ class HipTrainer:
                 self._graph, self._graph_b, self._static_out = hit
                 self._copy_into_static(batch)
             self._graph.replay()
+            L.mark("post_replay")
             for m in self._bns:                     # the replay runs no Python forward: count the batch for num_batches_tracked here
                 m._pending_batches += 1
             loss_dict = self._static_out
@@ -492,6 +495,7 @@ class HipTrainer:
             for h in late + early:
                 h.wait()
         self._optimizer()
+        L.mark("post_optimizer")
         return loss_dict
 
 

@@ -29,6 +29,7 @@ _PROTOS = {
     "sde_version": ([], c_int),
     "sde_mark_time": ([_P, _P], c_int),
     "sde_wall_clock_khz": ([], c_int),
+    "sde_store_u64": ([_P, ctypes.c_uint64, _P], c_int),
     "sde_resize": ([_P, _P, _I, _I, _I, _I, _I, _I, _P], c_int),
     "sde_pose_vec2mat": ([_P, _P, _I, _P], c_int),
     "sde_pose_vec2mat_bwd": ([_P, _P, _P, _I, _P], c_int),

@@ -176,3 +176,22 @@ def test_device_pipeline_at_kitti_size_through_the_prefetcher():
         assert torch.equal(got2[0][k], got[0][k])
     for i in range(2):
         assert torch.equal(got2[0]["ctx_img"][i], got[0]["ctx_img"][i]) and torch.equal(got2[0]["ctx_img_orig"][i], got[0]["ctx_img_orig"][i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots,ahead", [(4, 2), (3, 1), (2, 1), (3, 2)])
+def test_prefetcher_slot_ring_hands_over_every_batch_intact(slots, ahead):
+    """Eleven distinct batches through the slot ring (uploads staged `ahead` batches beyond the one in use, buffers rewritten behind the consumer's
+    release events): each batch, read when it is handed over and again after a kernel's worth of work, is the one the loader produced."""
+    from simpledepthestimation_amd.data import DevicePrefetcher
+    host = [{"a": torch.full((3, 257, 129), float(i)).pin_memory(), "b": [np.full((5, 7), i, dtype=np.int32), np.full((2,), -i, dtype=np.int64)], "flip": bool(i & 1)}
+            for i in range(11)]
+    seen = []
+    for i, b in enumerate(DevicePrefetcher(host, "cuda", slots=slots, ahead=ahead)):
+        assert b["flip"] == bool(i & 1) and b["a"].is_cuda
+        x = b["a"] * 2.0 + 1.0                        # work enqueued on the consumer's stream against the slot's tensors
+        seen.append((x.sum(), b["b"][0].sum(), b["b"][1].sum()))
+    torch.cuda.synchronize()
+    assert len(seen) == 11
+    for i, (x, s0, s1) in enumerate(seen):
+        assert float(x) == (2.0 * i + 1.0) * 3 * 257 * 129 and int(s0) == 35 * i and int(s1) == -2 * i
