@@ -448,9 +448,11 @@ def main():
             trainer.input_transform = aug
         # ONE loader / prefetcher iteration for warm-up and timed region: the pinned host buffers and the prefetcher's slot buffers are allocated (and
         # their first transfers paid) during the warm-up, as in a training run that has been going for a while
-        gen, h2d_bytes = host_loader(arch, args.batch, args.height, args.width, 2000 + rank, max(args.warmup, 4) + args.steps)
-        feed = iter(DevicePrefetcher(gen, device, device_aug=(aug if args.aug_on_copy_stream else None)))
-        for _ in range(max(args.warmup, 4)):
+        n_warm = max(args.warmup, 36)           # (covers the prefetcher's copy-stream selection: 32 batches)
+        gen, h2d_bytes = host_loader(arch, args.batch, args.height, args.width, 2000 + rank, n_warm + args.steps)
+        prefetcher = DevicePrefetcher(gen, device, device_aug=(aug if args.aug_on_copy_stream else None))
+        feed = iter(prefetcher)
+        for _ in range(n_warm):
             losses = trainer.step(next(feed))
     else:
         for _ in range(args.warmup):
@@ -497,7 +499,7 @@ def main():
             out["marks_us"] = {k: round(v, 1) for k, v in sorted(L.marks_read("step_start").items(), key=lambda kv: kv[1])}
         if args.with_loader:
             out["data"] = "synthetic uint8 frames at 375x1242 fed per step through the pinned host -> device prefetcher and the device resize + colour-jitter kernels"
-            out["input_side"] = {"h2d_bytes_per_step": h2d_bytes, "in_timed_region": True}
+            out["input_side"] = {"h2d_bytes_per_step": h2d_bytes, "in_timed_region": True, "copy_stream": getattr(prefetcher, "picked", None)}
         if args.profile_steps > 0:
             hbm, out["roofline"] = roofline_pass(trainer, batch, args.profile_steps, args.dtype, args.workload, step_ms=ms)
             if hbm is not None:

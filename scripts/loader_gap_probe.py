@@ -19,10 +19,12 @@ def run(workload, variant, n_warm=20, n=120):
     from simpledepthestimation_amd.data.device_aug import DeviceImageAug
     arch = bench.WORKLOADS[workload]["arch"]
     trainer.input_transform = DeviceImageAug(dev)
-    gen, _ = bench.host_loader(arch, 12, 192, 640, 1, n_warm + n)
+    gen, _ = bench.host_loader(arch, 12, 192, 640, 1, 2 * n_warm + n)
     import os
     skipped = [torch.cuda.Stream() for _ in range(int(os.environ.get("SKIP_STREAMS", "0")))]      # shift the pool index the copy stream gets
     pf = DevicePrefetcher(gen, dev, slots=int(os.environ.get("SLOTS", "4")), ahead=int(os.environ.get("AHEAD", "2")))
+    if variant == "priostream":          # copy stream from the high-priority pool from the start (before the graph exists)
+        pf._stream = torch.cuda.Stream(device=dev, priority=-1)
     orig = pf._stage
     cache = {}
     def stage(batch, slot):
@@ -126,20 +128,49 @@ def run(workload, variant, n_warm=20, n=120):
     for _ in range(n_warm):
         trainer.step(next(feed))
     torch.cuda.synchronize()
+    if variant in ("restream", "rebuf", "repin"):
+        # finer: only the copy stream / only the device slot buffers / only the pinned host batch replaced after the graph exists
+        if variant == "restream":
+            pf._stream = torch.cuda.Stream(device=dev)
+        elif variant == "rebuf":
+            pf._bufs = [dict() for _ in range(pf._slots)]
+        else:
+            gen2, _ = bench.host_loader(arch, 12, 192, 640, 3, 1)
+            fresh = next(iter(gen2))
+            pf.loader = (dict(fresh) for _ in range(n_warm + n))
+            it2 = iter(pf)
+            feed = it2
+        for _ in range(n_warm):
+            trainer.step(next(feed))
+        torch.cuda.synchronize()
+    if variant in ("reprefetch", "reprefetch_keep", "recapture"):
+        # which object of the first run carries the slow state?  reprefetch: same trainer, NEW host buffers + prefetcher (old ones released first);
+        # reprefetch_keep: new ones while the old ones stay alive; recapture: same prefetcher, the trainer's graph captured again
+        if variant == "recapture":
+            trainer._graphs = {}; trainer._static_batch = None
+        else:
+            if variant == "reprefetch":
+                del feed, pf, gen
+                import gc; gc.collect()
+            else:
+                keep = (feed, pf, gen)
+            gen, _ = bench.host_loader(arch, 12, 192, 640, 2, n_warm + n)
+            pf = DevicePrefetcher(gen, dev)
+            feed = iter(pf)
+        for _ in range(n_warm):
+            trainer.step(next(feed))
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     chunks, tc, i = [], t0, 0
     for hb in feed:
         trainer.step(hb)
         i += 1
-        if i % 40 == 0:                      # per-chunk rate (one sync per 40 steps): does the rate drift during the run?
-            torch.cuda.synchronize()
-            t = time.perf_counter(); chunks.append(round((t - tc) / 40 * 1e3, 3)); tc = t
     torch.cuda.synchronize()
     print("   per 40 steps:", chunks, flush=True)
     from simpledepthestimation_amd.hip import lib as L
     if L.MARKS is not None:
         print("   marks:", {k: round(v) for k, v in sorted(L.marks_read("step_start").items(), key=lambda kv: kv[1])}, flush=True)
-    return (time.perf_counter() - t0) / n * 1e3
+    return (time.perf_counter() - t0) / max(i, 1) * 1e3
 
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "mono_r18"

@@ -160,10 +160,18 @@ class DevicePrefetcher:
 
     _RAW = ("img_u8", "ctx_img_u8", "aug_params", "device_resize")     # consumed by device_aug (which uploads them itself)
 
-    def __init__(self, loader, device, device_aug=None, slots=4, ahead=2):
+    def __init__(self, loader, device, device_aug=None, slots=4, ahead=2, pick_stream=True):
         self.loader, self.device = loader, torch.device(device)
         self.device_aug = device_aug
         self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # Which copy stream: the HIP runtime multiplexes all streams onto four hardware queues, bound on first use, and an upload that shares the queue of
+        # the training stream (or of a critical branch of its step graph) holds back what is submitted behind it.  Measured with 50 MB of uploads per step
+        # (MonoDepth2-R18, resident inputs 4.05 ms/step): the stream created here, first used BEFORE the consumer captured its graph, 4.65; a stream first
+        # used once the graph is replaying 4.22 (= resident + the resize kernels).  Supervised-R50 the other way round: 6.60 against 7.05; a high-priority
+        # stream: MonoDepth2 4.22, Supervised 15 ms.  HIP offers no way to choose the queue, so the prefetcher tries both and keeps the faster one:
+        # batches 5-16 on this stream, 21-32 on a fresh one, judged by the median hand-over interval (the per-slot flags make a switch safe at any time).
+        # pick_stream=False keeps the first stream.  (profiles/r03x_loader_probe.txt)
+        self._pick = {"phase": 0, "t": [], "med": {}} if (pick_stream and self._stream is not None) else None
         self._slots = max(2, int(slots))
         # batches staged ahead of the one being consumed.  Two, not one: HIP streams share a handful of hardware queues, and an upload that lands on
         # the queue of one of the step graph's branches starts only when that branch has drained, i.e. at the END of the running step -- one batch
@@ -213,6 +221,28 @@ class DevicePrefetcher:
             self._signal(0, slot, seq)
         return out, seq
 
+    def _pick_stream(self, n):
+        """Copy-stream selection (see __init__): n = batches handed over so far, across re-iterations."""
+        import time
+        p = self._pick
+        p["count"] = k = p.get("count", 0) + 1
+        now = time.perf_counter()
+        if k in (5, 21):
+            p["t"] = [now]
+        elif 5 < k <= 16 or 21 < k <= 32:
+            p["t"].append(now)
+        if k == 16 or k == 32:
+            d = sorted(b - a for a, b in zip(p["t"], p["t"][1:]))
+            p["med"][p["phase"]] = d[len(d) // 2]
+            if k == 16:
+                p["first"], p["phase"] = self._stream, 1
+                self._stream = torch.cuda.Stream(device=self.device)
+            else:
+                if p["med"][1] > 0.99 * p["med"][0]:           # the fresh stream is not clearly better: back to the first one
+                    self._stream = p["first"]
+                self.picked = {"first_ms": p["med"][0] * 1e3, "fresh_ms": p["med"][1] * 1e3, "kept": "first" if self._stream is p["first"] else "fresh"}
+                self._pick = None
+
     def _signal(self, which, slot, seq):
         """Enqueue on the current stream: flags[which][slot] = seq once everything enqueued before has completed."""
         from ..hip import lib as L
@@ -245,6 +275,8 @@ class DevicePrefetcher:
             cur, seq = staged.popleft()
             slot = n % self._slots
             n += 1
+            if self._pick is not None:
+                self._pick_stream(n)
             stage_more()                            # the uploads of the next `ahead` batches are in flight before this one is handed over
             if seq is not None:
                 self._host_wait(0, slot, seq)       # the upload has completed (the host saw its flag): the consumer's stream needs no wait of its own
