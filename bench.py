@@ -421,6 +421,8 @@ def main():
             elif k == "photo_multi":            # --opt photo_multi=0 -> one photometric launch per scale (A/B)
                 from simpledepthestimation_amd.modeling.meta_arch import MonoDepth2 as MD
                 MD.MULTI_SCALE_PHOTO = bool(int(v))
+            elif k == "bias_defer":             # --opt bias_defer=0 -> every convolution's bias-gradient finalize as its own launch (A/B)
+                HN.BIAS_DEFER = bool(int(v))
             elif k == "head_bias":              # --opt head_bias=0 -> disparity-head bias gradients by the separate pass
                 HN.HEAD_BIAS_FUSED = bool(int(v))
             else:

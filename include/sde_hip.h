@@ -328,6 +328,15 @@ int sde_act_bwd_bias(const void* dout, const void* out, int act, long M, int C, 
 /* ... of an activation with two consumers (a decoder level feeds its disparity head and the next level): dz = act'(out) * (dout + dout1), dout1 may be NULL */
 int sde_act_bwd_bias_sum(const void* dout, const void* dout1, const void* out, int act, long M, int C, int dtype, void* dz, float* part, float* dbias, int Cbias,
                          int accumulate, sde_stream_t stream);
+/* part given but dbias == NULL: only the per-workgroup column partials are written ([sde_reduce_num_blocks(M, C)][C]); this call then sums the partial
+ * slabs of MANY layers in one launch (out[c] (+)= sum_rows part[r][c], c < C, every item exactly as the per-layer finalize sums it).  The per-layer
+ * finalize is a launch-sized kernel on the backward pass's serial chain that nothing downstream waits for.  `items` is a HOST array (copied by value). */
+typedef struct sde_colsum_item {
+    const float* part; /* [rows][ld] fp32 partial slab (device) */
+    float* out;        /* [C] destination (device) */
+    int32_t rows, ld, C, accumulate;
+} sde_colsum_item;
+int sde_colsum_finalize_batched(const sde_colsum_item* items, int n, sde_stream_t stream);
 
 /* Backward of ReflectionPad2d(1) [+ nearest x2 upsample + channel concat] (depth_decoder.py:L40-47,L102-105):
  * dxp [B,H+2,W+2,C] (gradient w.r.t. the padded virtual input, from the data-gradient GEMM) ->

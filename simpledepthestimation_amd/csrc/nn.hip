@@ -731,6 +731,29 @@ __global__ void __launch_bounds__(SLAB_T) colsum_finalize_kernel(const float* __
     out[c] = accumulate ? out[c] + (float)sv : (float)sv;
 }
 
+// The bias-gradient column sums of MANY layers in one launch (the per-layer finalize is a 5 us launch on the serial chain of the backward pass that nothing
+// downstream waits for): block ranges per item, every item summed exactly as colsum_finalize_kernel sums it.  The table travels by value.
+constexpr int COLSUM_MAX_ITEMS = 64;
+struct ColsumBatch {
+    const float* part[COLSUM_MAX_ITEMS];
+    float* out[COLSUM_MAX_ITEMS];
+    int rows[COLSUM_MAX_ITEMS], ld[COLSUM_MAX_ITEMS], C[COLSUM_MAX_ITEMS], accumulate[COLSUM_MAX_ITEMS];
+    int first[COLSUM_MAX_ITEMS + 1];
+    int n;
+};
+__global__ void __launch_bounds__(SLAB_T) colsum_finalize_batched_kernel(const ColsumBatch b) {
+    __shared__ double sh[SLAB_SH];
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.first[k + 1]) ++k;
+    const int col0 = ((int)blockIdx.x - b.first[k]) * 16;
+    slab_colsum16(b.part[k], b.rows[k], b.ld[k], col0, sh);
+    const int c = col0 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= b.C[k]) return;
+    const double sv = sh[SLAB_RES + threadIdx.x];
+    float* out = b.out[k];
+    out[c] = b.accumulate[k] ? out[c] + (float)sv : (float)sv;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Gradient folding for the decoder: reflection pad backward (+ nearest x2 upsample backward + concat split)
 //   dxp [B, H+2, W+2, C] is the gradient w.r.t. the reflection-PADDED virtual input (what the data-gradient GEMM emits).
@@ -1501,7 +1524,7 @@ int sde_act_bwd_bias_sum(const void* dout, const void* dout1, const void* out, i
     hipStream_t s = (hipStream_t)stream;
     const int nblk = sde_reduce_num_blocks(M, C);
     const long rpb = (M + nblk - 1) / nblk;
-    float* p = dbias ? part : nullptr;
+    float* p = part;                    // (part without dbias: the column partials only -- the caller sums them later, sde_colsum_finalize_batched)
     const size_t lds = ((size_t)C > 256 * 8 ? (size_t)C : 256 * 8) * sizeof(float);
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(act_bwd_bias_kernel<float>, dim3(nblk), dim3(256), lds, s, (const float*)dout, (const float*)dout1, (const float*)out, act, M, C, rpb, (float*)dz, p),
@@ -1513,6 +1536,28 @@ int sde_act_bwd_bias_sum(const void* dout, const void* dout1, const void* out, i
         const float* src = pre_reduce(part, rows, C, s);
         hipLaunchKernelGGL(colsum_finalize_kernel, dim3(sde_cdiv(Cbias, 16)), dim3(SLAB_T), 0, s, src, rows, C, Cbias, dbias, accumulate);
         SDE_CHECK_LAUNCH("sde_act_bwd_bias/finalize");
+    }
+    return SDE_OK;
+}
+
+int sde_colsum_finalize_batched(const sde_colsum_item* items, int n, sde_stream_t stream) {
+    SDE_CHECK_ARG(items && n >= 0, "sde_colsum_finalize_batched: bad argument");
+    for (int base = 0; base < n; base += COLSUM_MAX_ITEMS) {
+        ColsumBatch b;
+        b.n = n - base < COLSUM_MAX_ITEMS ? n - base : COLSUM_MAX_ITEMS;
+        b.first[0] = 0;
+        for (int k = 0; k < COLSUM_MAX_ITEMS; ++k) {
+            const bool on = k < b.n;
+            const sde_colsum_item* it = on ? items + base + k : nullptr;
+            SDE_CHECK_ARG(!on || (it->part && it->out && it->rows >= 1 && it->rows <= 4096 && it->C >= 1 && it->C <= it->ld),
+                          "sde_colsum_finalize_batched: item %d: bad slab (rows=%d ld=%d C=%d)", base + k, on ? it->rows : 0, on ? it->ld : 0, on ? it->C : 0);
+            b.part[k] = on ? it->part : nullptr; b.out[k] = on ? it->out : nullptr;
+            b.rows[k] = on ? it->rows : 0; b.ld[k] = on ? it->ld : 0; b.C[k] = on ? it->C : 0; b.accumulate[k] = on ? it->accumulate : 0;
+            b.first[k + 1] = b.first[k] + (on ? sde_cdiv(it->C, 16) : 0);
+        }
+        if (b.first[b.n] == 0) continue;
+        hipLaunchKernelGGL(colsum_finalize_batched_kernel, dim3(b.first[b.n]), dim3(SLAB_T), 0, (hipStream_t)stream, b);
+        SDE_CHECK_LAUNCH("sde_colsum_finalize_batched");
     }
     return SDE_OK;
 }

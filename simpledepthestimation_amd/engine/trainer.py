@@ -311,6 +311,7 @@ class HipTrainer:
                         torch.cuda.current_stream().wait_stream(st_)
                     self._wreduce.forked = False
                 self._wreduce.jobs, self._wreduce._seen = [], set()       # nothing left registered if backward raised
+                self._wreduce.bias_jobs, self._wreduce._seen_bias = [], set()
                 self._wreduce.queue, self._wreduce.groups_done = [], 0
 
     def _backward_rest(self):

@@ -42,6 +42,7 @@ L.register_protos({
     "sde_conv_wgrad": ([POINTER(ConvDesc), _P, _I, _I, _I, _P, _I, _P, _I, _P], c_int),
     "sde_conv_wgrad_partial": ([POINTER(ConvDesc), _P, _I, _I, _P, _I, _P], c_int),
     "sde_wgrad_reduce_batched": ([_P, _I, _P], c_int),
+    "sde_colsum_finalize_batched": ([_P, _I, _P], c_int),
     "sde_prep_input": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P], c_int),
     "sde_bn_finalize": ([_P, _I, _I, _LG, _P, _P, _P, _P, _F, _F, _P, _P], c_int),
     "sde_bn_eval_params": ([_P, _P, _P, _P, _F, _I, _P, _P], c_int),
@@ -289,8 +290,12 @@ class _Conv2d(torch.autograd.Function):
             bslot = _grad_slot(ctx.params[1]) if has_bias else None
             dbias = (bslot if bslot is not None else torch.empty(Cout, device=dev)) if has_bias else None
             dz = torch.empty_like(dy) if (act != ACT_NONE or dy1 is not None) else None
-            L.check(lib.sde_act_bwd_bias_sum(L.ptr(dy), L.ptr(dy1), L.ptr(y), act, M, ldy, dtype_code(dt), L.ptr(dz), L.ptr(part), L.ptr(dbias), Cout,
+            # the column partials' final sum is nothing the chain waits for: into a gradient slot it rides in the phase's ONE batched finalize (flush)
+            later = bslot is not None and WGRAD_DEFER is not None and BIAS_DEFER and L.PROFILE is None and WGRAD_DEFER.accepts_bias(bslot)
+            L.check(lib.sde_act_bwd_bias_sum(L.ptr(dy), L.ptr(dy1), L.ptr(y), act, M, ldy, dtype_code(dt), L.ptr(dz), L.ptr(part), None if later else L.ptr(dbias), Cout,
                                              int(bslot is not None), L.stream()), "sde_act_bwd_bias_sum")
+            if later:
+                WGRAD_DEFER.add_bias(part, nblk, ldy, Cout, bslot)
             if bslot is not None:
                 dbias = None
             if dz is None:
@@ -459,6 +464,13 @@ def _wptr(t):
     return c_void_p(t.data_ptr())
 
 
+BIAS_DEFER = True       # bias-gradient column sums of a backward phase in one launch at its end (False: one finalize launch per layer, on the chain)
+
+
+class ColsumItem(Structure):
+    _fields_ = [("part", c_void_p), ("out", c_void_p), ("rows", c_int32), ("ld", c_int32), ("C", c_int32), ("accumulate", c_int32)]
+
+
 class WReduceItem(Structure):
     _fields_ = [("slab", c_void_p), ("dw", c_void_p), ("rows", c_int32), ("Cout", c_int32), ("KHW", c_int32), ("Cin_pad", c_int32),
                 ("Cin_real", c_int32), ("accumulate", c_int32)]
@@ -474,6 +486,7 @@ class WGradReducer:
 
     def __init__(self):
         self.jobs, self._seen = [], set()
+        self.bias_jobs, self._seen_bias = [], set()      # (partial slab, rows, ld, C, gradient slot) of convolutions whose bias-gradient finalize is deferred
         self.forked = False        # some GEMM of this phase still runs on the side stream (late join)
         self.pending = []          # (event behind a layer's side-stream work, its operands) of convolutions whose join is lagging (SDE_JOIN_LAG)
         self.queue = []            # SDE_WGRAD_GROUP > 1: (launch closure, operands) of layers whose weight-gradient GEMM waits for its group's fork
@@ -509,6 +522,20 @@ class WGradReducer:
         # a weight used twice in one phase (shared modules) must not be accumulated by two blocks of one launch: the second use reduces at once
         return wslot.data_ptr() not in self._seen
 
+    def accepts_bias(self, bslot):
+        # (a bias used twice in one phase must not be accumulated by two blocks of one launch)
+        return bslot.data_ptr() not in self._seen_bias
+
+    def add_bias(self, part, rows, ld, C, bslot):
+        self._seen_bias.add(bslot.data_ptr())
+        self.bias_jobs.append((part, rows, ld, C, bslot))
+
+    def flush_bias(self):
+        if self.bias_jobs:
+            arr = (ColsumItem * len(self.bias_jobs))(*[ColsumItem(p.data_ptr(), b.data_ptr(), r, ld, C, 1) for p, r, ld, C, b in self.bias_jobs])
+            L.check(L.lib().sde_colsum_finalize_batched(arr, len(self.bias_jobs), L.stream()), "sde_colsum_finalize_batched")
+        self.bias_jobs, self._seen_bias = [], set()
+
     def add(self, slab, src_ptr, rows, wslot, Cout, KHW, Cin_pad, Cin_real, flags=1):
         self._seen.add(wslot.data_ptr())
         self.jobs.append((slab, wslot, (src_ptr, wslot.data_ptr(), rows, Cout, KHW, Cin_pad, Cin_real, flags)))
@@ -521,6 +548,7 @@ class WGradReducer:
             for st_ in L.all_side_streams():
                 torch.cuda.current_stream().wait_stream(st_)
             self.forked = False
+        self.flush_bias()
         if not self.jobs:
             return
         items = []
