@@ -435,6 +435,10 @@ int sde_loss_scale_update(float* scale_state, float growth_factor, float backoff
  * orig may be NULL.  Two launches (the contrast step needs the frame's mean luminance at that point of the chain), no host synchronisation. */
 int sde_image_prep_u8(const uint8_t* src, int N, int Hs, int Ws, int h, int w, const int* xtab, const int* ytab, const float* jit, unsigned* lsum, float* img,
                       float* orig, sde_stream_t stream);
+/* G <= 4 frame tensors of one shape and one parameter set per sample (a MonoDepth2 batch: target frames + context frames) in ONE pair of launches:
+ * src / img / orig are HOST arrays of G device pointers (orig NULL: none), lsum [G*N]. */
+int sde_image_prep_u8_multi(const uint8_t* const* src, int G, int N, int Hs, int Ws, int h, int w, const int* xtab, const int* ytab, const float* jit, unsigned* lsum,
+                            float* const* img, float* const* orig, sde_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Evaluation: detectron2/evaluation/depth_evaluation.py:L74-104 kitti_evaluator.process for ONE image, with

@@ -21,14 +21,17 @@
 
 namespace {
 
+constexpr int PREP_MAX_GROUPS = 4;
 struct PrepArgs {
-    const uint8_t* src;          // [N][Hs][Ws][3]
+    // G groups of N frames each (a MonoDepth2 batch: the target frames and the two context-frame tensors) share the size pair, the tap tables and the
+    // per-sample jitter parameters; blockIdx.z = group * N + sample
+    const uint8_t* src[PREP_MAX_GROUPS];          // [N][Hs][Ws][3]
     const int* xtab;             // [w][4]: x0, x1, a0, a1   (OpenCV INTER_LINEAR taps / 11-bit weights, host-built once per (Ws, w))
     const int* ytab;             // [h][4]: y0, y1, b0, b1
     const float* jit;            // [N][8]: brightness, contrast, saturation, hue factors, then the order of the four steps (0..3 as floats; < 0: no jitter)
-    unsigned* lsum;              // [N] workspace: sum of L over the frame at the contrast step
-    float* img;                  // [N][3][h][w] jittered / 255
-    float* orig;                 // [N][3][h][w] un-jittered / 255 (may be null)
+    unsigned* lsum;              // [G][N] workspace: sum of L over the frame at the contrast step
+    float* img[PREP_MAX_GROUPS];                  // [N][3][h][w] jittered / 255
+    float* orig[PREP_MAX_GROUPS];                 // [N][3][h][w] un-jittered / 255 (may be null)
     int N, Hs, Ws, h, w;
 };
 
@@ -121,12 +124,12 @@ __device__ __forceinline__ int contrast_pos(const float* jp) {
 constexpr int P0_ROWS = 32;
 __global__ void __launch_bounds__(256) image_prep_mean_kernel(PrepArgs a) {
     __shared__ unsigned red[4];
-    const int n = blockIdx.z;
+    const int grp = blockIdx.z / a.N, n = blockIdx.z % a.N;
     const float* jp = a.jit + n * 8;
     const bool jitter = jp[4] >= 0.f;
     const int cpos = jitter ? contrast_pos(jp) : 4;
     if (!(jitter && cpos < 4)) return;                       // uniform per frame: no contrast step, nothing to sum
-    const uint8_t* frame = a.src + (size_t)n * a.Hs * a.Ws * 3;
+    const uint8_t* frame = a.src[grp] + (size_t)n * a.Hs * a.Ws * 3;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     unsigned l = 0;
     if (x < a.w)
@@ -139,46 +142,59 @@ __global__ void __launch_bounds__(256) image_prep_mean_kernel(PrepArgs a) {
     for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(a.lsum + n, red[0] + red[1] + red[2] + red[3]);      // integer: exact and order-independent
+    if (threadIdx.x == 0) atomicAdd(a.lsum + blockIdx.z, red[0] + red[1] + red[2] + red[3]);      // integer: exact and order-independent
 }
 
 __global__ void __launch_bounds__(256) image_prep_kernel(PrepArgs a) {
-    const int n = blockIdx.z;
+    const int grp = blockIdx.z / a.N, n = blockIdx.z % a.N;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (!(x < a.w && y < a.h)) return;
     const float* jp = a.jit + n * 8;
     const bool jitter = jp[4] >= 0.f;
     const int cpos = jitter ? contrast_pos(jp) : 4;
-    const uint8_t* frame = a.src + (size_t)n * a.Hs * a.Ws * 3;
+    const uint8_t* frame = a.src[grp] + (size_t)n * a.Hs * a.Ws * 3;
     int r, g, b;
     resize_px(a, frame, y, x, r, g, b);
     const size_t hw = (size_t)a.h * a.w, o0 = (size_t)n * 3 * hw + (size_t)y * a.w + x;
-    if (a.orig) { a.orig[o0] = (float)r / 255.0f; a.orig[o0 + hw] = (float)g / 255.0f; a.orig[o0 + 2 * hw] = (float)b / 255.0f; }
+    float* __restrict__ orig = a.orig[grp];
+    float* __restrict__ img = a.img[grp];
+    if (orig) { orig[o0] = (float)r / 255.0f; orig[o0 + hw] = (float)g / 255.0f; orig[o0 + 2 * hw] = (float)b / 255.0f; }
     if (jitter) {
         // ImageStat.Stat(L image).mean[0] = sum / count in double; int(mean + 0.5)
-        const int mean = cpos < 4 ? (int)((double)a.lsum[n] / (double)(a.h * a.w) + 0.5) : 0;
+        const int mean = cpos < 4 ? (int)((double)a.lsum[blockIdx.z] / (double)(a.h * a.w) + 0.5) : 0;
         jitter_steps(jp, 0, 4, mean, r, g, b);
     }
-    a.img[o0] = (float)r / 255.0f; a.img[o0 + hw] = (float)g / 255.0f; a.img[o0 + 2 * hw] = (float)b / 255.0f;
+    img[o0] = (float)r / 255.0f; img[o0 + hw] = (float)g / 255.0f; img[o0 + 2 * hw] = (float)b / 255.0f;
 }
 
 }  // namespace
 
 extern "C" {
 
-int sde_image_prep_u8(const uint8_t* src, int N, int Hs, int Ws, int h, int w, const int* xtab, const int* ytab, const float* jit, unsigned* lsum, float* img,
-                      float* orig, sde_stream_t stream) {
-    SDE_CHECK_ARG(src && xtab && ytab && jit && lsum && img && N > 0 && N <= 65535 && Hs > 0 && Ws > 0 && h > 0 && w > 0, "sde_image_prep_u8: bad argument");
+int sde_image_prep_u8_multi(const uint8_t* const* src, int G, int N, int Hs, int Ws, int h, int w, const int* xtab, const int* ytab, const float* jit, unsigned* lsum,
+                            float* const* img, float* const* orig, sde_stream_t stream) {
+    SDE_CHECK_ARG(src && img && G >= 1 && G <= PREP_MAX_GROUPS && xtab && ytab && jit && lsum && N > 0 && (long)N * G <= 65535 && Hs > 0 && Ws > 0 && h > 0 && w > 0,
+                  "sde_image_prep_u8: bad argument (G=%d N=%d)", G, N);
     SDE_CHECK_ARG((long)Hs * Ws * 3 * N < 0x7fffffffL && (((uintptr_t)xtab | (uintptr_t)ytab) & 15) == 0, "sde_image_prep_u8: batch too large or unaligned tap tables");
-    PrepArgs a{src, xtab, ytab, jit, lsum, img, orig, N, Hs, Ws, h, w};
+    PrepArgs a{};
+    a.xtab = xtab; a.ytab = ytab; a.jit = jit; a.lsum = lsum; a.N = N; a.Hs = Hs; a.Ws = Ws; a.h = h; a.w = w;
+    for (int g = 0; g < PREP_MAX_GROUPS; ++g) {
+        SDE_CHECK_ARG(g >= G || (src[g] && img[g]), "sde_image_prep_u8: null source / destination of group %d", g);
+        a.src[g] = g < G ? src[g] : nullptr; a.img[g] = g < G ? img[g] : nullptr; a.orig[g] = (g < G && orig) ? orig[g] : nullptr;
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(lsum, 0, sizeof(unsigned) * N, s) != hipSuccess) { sde_set_error("sde_image_prep_u8: memset failed"); return SDE_ERR_LAUNCH; }
-    const dim3 grid((unsigned)sde_cdiv(w, 64), (unsigned)sde_cdiv(h, 4), (unsigned)N);
-    hipLaunchKernelGGL(image_prep_mean_kernel, dim3((unsigned)sde_cdiv(w, 64), (unsigned)sde_cdiv(h, P0_ROWS), (unsigned)N), dim3(256), 0, s, a);
+    if (hipMemsetAsync(lsum, 0, sizeof(unsigned) * N * G, s) != hipSuccess) { sde_set_error("sde_image_prep_u8: memset failed"); return SDE_ERR_LAUNCH; }
+    hipLaunchKernelGGL(image_prep_mean_kernel, dim3((unsigned)sde_cdiv(w, 64), (unsigned)sde_cdiv(h, P0_ROWS), (unsigned)(N * G)), dim3(256), 0, s, a);
     SDE_CHECK_LAUNCH("sde_image_prep_u8/mean");
-    hipLaunchKernelGGL(image_prep_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(image_prep_kernel, dim3((unsigned)sde_cdiv(w, 64), (unsigned)sde_cdiv(h, 4), (unsigned)(N * G)), dim3(256), 0, s, a);
     SDE_CHECK_LAUNCH("sde_image_prep_u8");
     return SDE_OK;
+}
+
+int sde_image_prep_u8(const uint8_t* src, int N, int Hs, int Ws, int h, int w, const int* xtab, const int* ytab, const float* jit, unsigned* lsum, float* img,
+                      float* orig, sde_stream_t stream) {
+    SDE_CHECK_ARG(src && img, "sde_image_prep_u8: null source / destination");
+    return sde_image_prep_u8_multi(&src, 1, N, Hs, Ws, h, w, xtab, ytab, jit, lsum, &img, orig ? &orig : nullptr, stream);
 }
 
 }  // extern "C"

@@ -14,7 +14,9 @@ from ..hip import lib as L
 from .preprocess.augmentation import _linear_coefs
 
 _P, _I = L.c_void_p, L.c_int
-L.register_protos({"sde_image_prep_u8": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], L.c_int)})
+L.register_protos({"sde_image_prep_u8": ([_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], L.c_int),
+                   "sde_image_prep_u8_multi": ([_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P], L.c_int)})
+PREP_MAX_GROUPS = 4
 
 
 def tap_table(src, dst):
@@ -68,6 +70,31 @@ class DeviceImageAug:
                                           L.ptr(img), L.ptr(orig), L.stream()), "sde_image_prep_u8")
         return img, orig
 
+    def prep_multi(self, frames_list, params, h, w, bufs=None, tag="x", outs=None):
+        """G <= 4 uint8 device tensors [N,Hs,Ws,3] of ONE shape sharing the per-sample parameters (target + context frames of a batch) in one pair of
+        launches -> [(img, orig)] per tensor.  outs: optional list of (img, orig) destinations (or None entries)."""
+        G = len(frames_list)
+        f0 = frames_list[0]
+        if not (1 <= G <= PREP_MAX_GROUPS) or any(f.dtype != torch.uint8 or f.dim() != 4 or f.shape != f0.shape or not f.is_cuda for f in frames_list):
+            raise L.SdeHipError("DeviceImageAug: prep_multi takes 1-4 uint8 [N,H,W,3] device tensors of one shape")
+        N, Hs, Ws, _ = f0.shape
+        frames_list = [f.contiguous() for f in frames_list]
+        params = params.contiguous().float()
+        ok = lambda t: torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == (N, 3, h, w) and t.is_contiguous()
+        res = []
+        for g in range(G):
+            o = outs[g] if outs is not None else None
+            if o is not None and ok(o[0]) and ok(o[1]):
+                res.append((o[0], o[1]))
+            else:
+                res.append((self._buf(bufs, ("aug.img", tag, g), (N, 3, h, w), torch.float32, self.device),
+                            self._buf(bufs, ("aug.orig", tag, g), (N, 3, h, w), torch.float32, self.device)))
+        lsum = self._buf(bufs, ("aug.lsum", tag), (G * N,), torch.int32, self.device)
+        arr = lambda ts: (L.c_void_p * G)(*[t.data_ptr() for t in ts])
+        L.check(L.lib().sde_image_prep_u8_multi(arr(frames_list), G, N, Hs, Ws, h, w, L.ptr(self.taps(Ws, w)), L.ptr(self.taps(Hs, h)), L.ptr(params), L.ptr(lsum),
+                                                arr([r[0] for r in res]), arr([r[1] for r in res]), L.stream()), "sde_image_prep_u8_multi")
+        return res
+
     def _up(self, t, bufs, key):
         """Host tensor -> (the slot's persistent) device tensor, asynchronously from pinned memory."""
         if isinstance(t, np.ndarray):
@@ -100,10 +127,15 @@ class DeviceImageAug:
         if torch.is_tensor(frames):
             # collated form (every frame of the batch has one source size; the collator stacked them, the loader pinned them): target frames
             # [B,Hs,Ws,3], contexts as a list of such tensors -- one upload and one pair of launches per tensor, outputs are the batch entries
-            out["img"], out["img_orig"] = self.prep(self._up(frames, bufs, "img"), pd, h, w, bufs, "img", dst("img", "img_orig"))
+            dev_frames = [self._up(frames, bufs, "img")] + [self._up(c, bufs, ("ctx", i)) for i, c in enumerate(ctx or [])]
+            dsts = [dst("img", "img_orig")] + [dst("ctx_img", "ctx_img_orig", i) for i in range(len(dev_frames) - 1)]
+            if len(dev_frames) <= PREP_MAX_GROUPS and all(f.shape == dev_frames[0].shape for f in dev_frames):
+                res = self.prep_multi(dev_frames, pd, h, w, bufs, "batch", dsts)            # target + context frames: ONE pair of launches
+            else:
+                res = [self.prep(f, pd, h, w, bufs, ("t", i), dsts[i]) for i, f in enumerate(dev_frames)]
+            out["img"], out["img_orig"] = res[0]
             if ctx is not None:
-                res = [self.prep(self._up(c, bufs, ("ctx", i)), pd, h, w, bufs, ("ctx", i), dst("ctx_img", "ctx_img_orig", i)) for i, c in enumerate(ctx)]
-                out["ctx_img"], out["ctx_img_orig"] = [r[0] for r in res], [r[1] for r in res]
+                out["ctx_img"], out["ctx_img_orig"] = [r[0] for r in res[1:]], [r[1] for r in res[1:]]
             return out
         B = len(frames)
         nctx = len(ctx[0]) if ctx is not None else 0
