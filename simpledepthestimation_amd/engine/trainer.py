@@ -268,7 +268,7 @@ class HipTrainer:
         if self._one is None or self._one.dtype != losses.dtype or self._one.device != losses.device or self._one.shape != losses.shape:
             self._one = torch.ones_like(losses)         # d loss / d loss, kept: backward() would launch a fill for it every step
         L.mark("loss_fwd_end")
-        self._backward(lambda: losses.backward(gradient=self._one))
+        self._backward(lambda: losses.backward(gradient=self._one), first_of_two=self._cut is not None)
         L.mark("bwd_joined")
         if self._packer is None and self.batch_pack:
             try:
@@ -277,18 +277,20 @@ class HipTrainer:
                 self.batch_pack = False             # model without HIP convolutions
         return loss_dict
 
-    def _backward(self, run):
+    def _backward(self, run, first_of_two=False):
         """One backward phase with the convolutions' weight-gradient reductions deferred to a single launch at its end."""
         HN.WGRAD_DEFER = self._wreduce
         # the fork / lagging-join bookkeeping of the weight-gradient side stream (hip/nn.py) is written against ONE main stream: every
         # convolution's backward must run on the stream this phase started on
         HN.MAIN_STREAM = torch.cuda.current_stream() if self.device.type == "cuda" else None
+        tag = "" if self._cut is None else ("A_" if first_of_two else "B_")       # (marker names per phase of a two-phase backward)
         try:
+            L.mark(tag + "bwd_start")
             run()
             if L.MARKS is not None:                  # diagnostic timeline (bench.py --marks): the last work of each stream of the phase
-                L.mark("bwd_main_end")
+                L.mark(tag + "bwd_main_end")
                 capturing = torch.cuda.is_current_stream_capturing()
-                for name, st_ in [("bwd_side_end", L.side_stream())] + ([("bwd_aux_end", L.aux_stream())] if L.AUX_USED else []):
+                for name, st_ in [(tag + "bwd_side_end", L.side_stream())] + ([(tag + "bwd_aux_end", L.aux_stream())] if L.AUX_USED else []):
                     with torch.cuda.stream(st_):
                         if torch.cuda.is_current_stream_capturing() == capturing:      # (a helper stream this phase never forked is not part of the capture)
                             L.mark(name)
@@ -313,6 +315,7 @@ class HipTrainer:
                 self._wreduce.jobs, self._wreduce._seen = [], set()       # nothing left registered if backward raised
                 self._wreduce.bias_jobs, self._wreduce._seen_bias = [], set()
                 self._wreduce.queue, self._wreduce.groups_done = [], 0
+            L.mark(tag + "bwd_end")
 
     def _backward_rest(self):
         self._backward(self._cut.backward_rest)
