@@ -403,6 +403,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
+    if os.environ.get("SDE_BENCH_STACKS"):          # debugging aid: every N seconds the Python stacks of all threads on stderr (where does a slow step sit?)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SDE_BENCH_STACKS"]), repeat=True)
 
     if args.no_side_stream or args.no_pgemm or args.opt or args.const:
         from simpledepthestimation_amd.hip import lib as L, nn as HN

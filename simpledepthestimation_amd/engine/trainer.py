@@ -496,6 +496,14 @@ class HipTrainer:
             else:
                 self._backward_rest()
             early = self._allreduce(0, self.late_start, wait=False, reverse=True)
+            if os.environ.get("SDE_DIST_DEBUG"):          # debugging aid: host time spent waiting for each bucket's collective
+                import time
+                ts = []
+                for h in late + early:
+                    t = time.perf_counter(); h.wait(); ts.append(round((time.perf_counter() - t) * 1e3, 1))
+                if self.rank == 0 if hasattr(self, "rank") else dist.get_rank() == 0:
+                    print(f"[dist] waits ms late {ts[:len(late)]} early {ts[len(late):]} ranges late {self.bucket_ranges(self.late_start, self.numel, True)} "
+                          f"early {self.bucket_ranges(0, self.late_start, True)}", flush=True)
             for h in late + early:
                 h.wait()
         self._optimizer()
