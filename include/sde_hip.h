@@ -251,6 +251,8 @@ int sde_conv_set_halo_min_blocks(int min_blocks);
                                   kernel (csrc/wgrad_dma.hip); 0: the register-staged kernel */
 #define SDE_OPT_BNBWD_FUSE 10  /* 1 (default): sde_conv_dgrad_bnbwd_rows reports the layers whose data gradient can carry BatchNorm's backward reduction
                                 * in its epilogue; 0: it reports none (the separate bn_bwd_reduce pass runs everywhere: A/B, tests) */
+#define SDE_OPT_CU_RESERVE 11  /* compute units the persistent kernels (pgemm, chalo, whalo) leave free: their grids are sized for (CUs - n) instead of every CU.
+                                * 0 (default); a multiple of 8 <= 128.  For data-parallel runs: RCCL's channel kernels otherwise wait for a resident workgroup to end */
 int sde_conv_set_option(int key, int value);
 
 /* dW (master fp32 OIHW, [Cout,Cin_real,KH,KW]) (+)= sum over output pixels of dy^T * im2col(virtual input).

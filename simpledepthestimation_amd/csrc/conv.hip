@@ -1776,8 +1776,9 @@ int sde_conv_set_option(int key, int value) {
         return old;
     }
     int* slot = key == SDE_OPT_PGEMM ? &g_use_pgemm : key == SDE_OPT_PGEMM_DEPTH ? &g_pgemm_depth : key == SDE_OPT_PGEMM_3X3 ? &g_pgemm_3x3 :
-                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : key == SDE_OPT_CONV_SMALL ? &g_conv_small : key == SDE_OPT_WGRAD_DMA ? &g_wgrad_dma : key == SDE_OPT_BNBWD_FUSE ? &g_bnbwd_fuse : nullptr;
+                key == SDE_OPT_PGEMM_TILE ? &sdeconv::g_pgemm_force_tile : key == SDE_OPT_SPLITK ? &g_splitk : key == SDE_OPT_WGRAD_HALO ? &g_wgrad_halo : key == SDE_OPT_CONV_SMALL ? &g_conv_small : key == SDE_OPT_WGRAD_DMA ? &g_wgrad_dma : key == SDE_OPT_BNBWD_FUSE ? &g_bnbwd_fuse : key == SDE_OPT_CU_RESERVE ? &sdeconv::g_cu_reserve : nullptr;
     SDE_CHECK_ARG(slot, "sde_conv_set_option: unknown key %d", key);
+    SDE_CHECK_ARG(key != SDE_OPT_CU_RESERVE || (value >= 0 && value <= 128 && value % 8 == 0), "sde_conv_set_option: CU reserve must be a multiple of 8 in [0, 128], got %d", value);
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_DEPTH || value == 3 || value == 4, "sde_conv_set_option: ring depth must be 3 or 4");
     SDE_CHECK_ARG(key != SDE_OPT_PGEMM_TILE || value == 0 || value == 64064 || value == 128064 || value == 128128, "sde_conv_set_option: bad tile %d", value);
     const int old = *slot;

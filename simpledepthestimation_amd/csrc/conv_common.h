@@ -5,6 +5,12 @@
 
 namespace sdeconv {
 
+// Compute units the persistent kernels size their grids for: the device's count (256 on MI355X) minus SDE_OPT_CU_RESERVE -- a data-parallel run can leave
+// some to RCCL's channel kernels, which otherwise queue behind workgroups that stay resident for a whole launch.  Multiples of 8 (one per XCD) keep the XCD-aware
+// tile order; with a reserve the in-register statistics path of pgemm applies to fewer layer shapes (its divisibility condition), results are the same.
+extern int g_cu_reserve;
+int sde_persistent_cus();      // (pgemm.hip)
+
 __device__ __forceinline__ int reflect1(int i, int n) {
     if (i < 0) i = -i;
     if (i >= n) i = 2 * (n - 1) - i;

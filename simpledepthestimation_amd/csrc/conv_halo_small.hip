@@ -227,7 +227,8 @@ static void ch_launch(const CHaloP& p, hipStream_t s) {
     }
     int per_cu = (160 * 1024) / lds;
     per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);
-    const int grid = p.total < 256 * per_cu ? p.total : 256 * per_cu;
+    const int cap = sde_persistent_cus() * per_cu;
+    const int grid = p.total < cap ? p.total : cap;
     hipLaunchKernelGGL((chalo_kernel<T16, CIN, CB>), dim3(grid), dim3(CH_THREADS), lds, s, p);
 }
 

@@ -645,7 +645,7 @@ static int pg_grid_max(int BM, int BN, int D) {
 #ifndef PG_MAX_PER_CU
 #define PG_MAX_PER_CU 4
 #endif
-    return 256 * (per_cu < 1 ? 1 : (per_cu > PG_MAX_PER_CU ? PG_MAX_PER_CU : per_cu));
+    return sde_persistent_cus() * (per_cu < 1 ? 1 : (per_cu > PG_MAX_PER_CU ? PG_MAX_PER_CU : per_cu));
 }
 
 static bool pg_stats_acc(int tiles_n, int tiles_mn, int ksplit, int src, int BM, int BN, int D) {
@@ -709,6 +709,17 @@ int pgemm_src_kind(const Gather& g) {
 // tiles" measured 6.55-6.58 against 6.58-6.60 ms (Supervised-R50), 4.34 against 4.27 (MonoDepth2-R18), 7.70 against 7.67 (MonoDepth2-R50): next to the
 // weight-gradient queue the bigger workgroups lose what they win alone, so the rule is NOT applied; the instantiations stay reachable through
 // SDE_OPT_PGEMM_TILE (tests/test_gpu_pgemm.py covers them).
+int g_cu_reserve = 0;           // sde_conv_set_option(SDE_OPT_CU_RESERVE, n)
+int sde_persistent_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cus = n;
+    }
+    const int left = cus - g_cu_reserve;
+    return left < 8 ? 8 : left;
+}
 int g_pgemm_force_tile = 0;     // sde_conv_set_option(SDE_OPT_PGEMM_TILE, 64064 | 128064 | 128128 | 0 = automatic)
 int pgemm_tile(const Gather& g, int ldy) {
     (void)g; (void)ldy;

@@ -236,7 +236,7 @@ int whalo_splits(const Gather& g, int Cout) {
     const int NB = wh_nb(g), CO16 = Cout > 16 ? 2 : 1;
     const int total = g.Bn * sde_cdiv(g.OH, WH_TH) * sde_cdiv(g.OW, WH_TW);
     const int per_cu = wh_lds(NB, CO16) * 2 <= 160 * 1024 ? 2 : 1;
-    const int grid = 256 * per_cu;
+    const int grid = sde_persistent_cus() * per_cu;
     return total < grid ? total : grid;
 }
 

@@ -74,7 +74,7 @@ class HipTrainer:
     """Owns the flat buffers and runs one training step: loss dict = trainer.step(batch)."""
 
     def __init__(self, model, groups, adamw=False, betas=(0.9, 0.999), eps=1e-8, bucket_mb=64, use_graph=False, skip_unused=(".fc.",),
-                 adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None, amp=False, init_scale=65536.0, growth_interval=2000, pose_stream=True):
+                 adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None, amp=False, init_scale=65536.0, growth_interval=2000, pose_stream=True, cu_reserve=None):
         self.model = model
         kinds = {type(m).__name__ for m in model.modules()}
         L.apply_schedule("packnet" if "PackNet01" in kinds else "resnet" if ("Bottleneck" in kinds or "BasicBlock" not in kinds) else "resnet_basic")
@@ -148,6 +148,13 @@ class HipTrainer:
         # data-parallel path as well: PoseNet's backward does not depend on the cut features, so all of it runs in phase A on the auxiliary
         # stream and _backward joins that stream before phase A's slab reduction -- its gradients are final when the late all-reduce starts
         self.pose_stream = bool(pose_stream) and adam_fn is None
+        # data-parallel runs: compute units the persistent kernels leave to RCCL's channel kernels (SDE_OPT_CU_RESERVE).  Off unless asked for: its
+        # effect can only be measured on a multi-GPU node (SDE_CU_RESERVE=<multiple of 8>, or HipTrainer(cu_reserve=...))
+        if cu_reserve is None:
+            cu_reserve = int(os.environ.get("SDE_CU_RESERVE", "0")) if self.world > 1 else 0
+        self.cu_reserve = int(cu_reserve)
+        if self.cu_reserve and dev.type == "cuda":
+            HN.set_option(HN.OPT_CU_RESERVE, self.cu_reserve)
         self._graph_b = None
         self._graph = None
         self._graphs = {}

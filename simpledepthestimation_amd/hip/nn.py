@@ -82,7 +82,7 @@ L.register_protos({
 })
 
 
-OPT_PGEMM, OPT_PGEMM_DEPTH, OPT_PGEMM_3X3, OPT_PGEMM_TILE, OPT_SPLITK, OPT_WGRAD_BLOCKS, OPT_WGRAD_HALO, OPT_CONV_SMALL, OPT_WGRAD_DMA, OPT_BNBWD_FUSE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10      # SDE_OPT_* of include/sde_hip.h
+OPT_PGEMM, OPT_PGEMM_DEPTH, OPT_PGEMM_3X3, OPT_PGEMM_TILE, OPT_SPLITK, OPT_WGRAD_BLOCKS, OPT_WGRAD_HALO, OPT_CONV_SMALL, OPT_WGRAD_DMA, OPT_BNBWD_FUSE, OPT_CU_RESERVE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11      # SDE_OPT_* of include/sde_hip.h
 
 
 def set_option(key, value):

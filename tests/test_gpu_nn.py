@@ -919,3 +919,37 @@ def test_maxpool_two_consumers(NN, dtype):
     assert torch.equal(nchw(ya, C), yr.detach()) and ya.data_ptr() == yb.data_ptr()
     torch.autograd.backward([ya, yb], [nhwc(g0, dtype, V), nhwc(g1, dtype, V)])
     check(nchw(xd.grad, C), xr.grad, dtype, "maxpool dx (two consumers)", 1e-6, 2e-2)
+
+
+@pytest.mark.parametrize("reserve", [32, 64])
+def test_persistent_kernels_with_a_cu_reserve(NN, reserve):
+    """SDE_OPT_CU_RESERVE: the persistent GEMM / halo kernels sized for fewer compute units (what a data-parallel run leaves to RCCL) -- conv + BatchNorm
+    statistics + both gradients at a shape with more tiles than workgroups, against the same calls without a reserve."""
+    g = torch.Generator().manual_seed(reserve)
+    B, H, W, Cin, C = 12, 48, 160, 64, 64
+    x = (torch.randn(B, H, W, Cin, generator=g) * 0.5).bfloat16().to(dev)
+    w = (torch.randn(C, Cin, 1, 1, generator=g) / 8).to(dev)
+    w3 = (torch.randn(16, 16, 3, 3, generator=g) / 12).to(dev)
+    x16 = (torch.randn(4, 96, 320, 16, generator=g) * 0.5).bfloat16().to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+
+    def run():
+        xd, wd, gd, bd = x.clone().requires_grad_(True), w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        y, stats = NN.conv2d(xd, wd, None, stride=1, pad=0, bn_stats=True)                       # pgemm 1x1: 1440 tiles
+        out = NN.batch_norm_act(y, stats, gd, bd, torch.zeros(C, device=dev), torch.ones(C, device=dev), relu=True)
+        xs, ws = x16.clone().requires_grad_(True), w3.clone().requires_grad_(True)
+        ys = NN.conv2d(xs, ws, None, stride=1, pad=1, reflect=True)                              # chalo / whalo: the small-channel halo kernels
+        (out.float().square().mean() + ys.float().square().mean()).backward()
+        torch.cuda.synchronize()
+        return [t.detach().float().cpu() for t in (out, ys, xd.grad, wd.grad, gd.grad, bd.grad, xs.grad, ws.grad)]
+    ref = run()
+    old = NN.set_option(NN.OPT_CU_RESERVE, reserve)
+    try:
+        got = run()
+    finally:
+        NN.set_option(NN.OPT_CU_RESERVE, old)
+    for name, a, b in zip(("out", "y_small", "dx", "dw", "dgamma", "dbeta", "dx_small", "dw_small"), got, ref):
+        tol = 2e-2 * float(b.abs().max()) + 1e-6           # bf16 storage; the order of the fp32 partial sums follows the grid
+        assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), tol)
+    with pytest.raises(Exception):
+        NN.set_option(NN.OPT_CU_RESERVE, 12)
