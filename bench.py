@@ -426,6 +426,8 @@ def main():
                 MD.MULTI_SCALE_PHOTO = bool(int(v))
             elif k == "bias_defer":             # --opt bias_defer=0 -> every convolution's bias-gradient finalize as its own launch (A/B)
                 HN.BIAS_DEFER = bool(int(v))
+            elif k == "resbn":                  # --opt resbn=0 -> residual BatchNorms keep their own backward reduce pass (A/B)
+                HN.RESBN_FUSED = bool(int(v))
             elif k == "head_bias":              # --opt head_bias=0 -> disparity-head bias gradients by the separate pass
                 HN.HEAD_BIAS_FUSED = bool(int(v))
             else:

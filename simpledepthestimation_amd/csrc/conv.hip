@@ -1498,7 +1498,7 @@ static int conv_fwd_impl(const sde_conv_desc* d, const void* w_packed, const flo
     p.w = w_packed; p.bias = bias; p.y = y; p.stats = stats; p.Cout = Cout; p.ldy = ldy; p.act = act;
     p.ksplit = 1; p.ws = nullptr;
     p.no_kfull = 0;
-    p.bn_y = nullptr; p.bnp = nullptr;
+    p.bn_y = nullptr; p.bnp = nullptr; p.bn_gb = nullptr; p.bn_out = nullptr;
     const int S = ws ? pick_ksplit(p.g, d->dtype, ldy) : 1;
     if (S > 1) {
         SDE_CHECK_ARG(ws_bytes >= (size_t)S * p.g.M * ldy * sizeof(float), "sde_conv_fwd_ws: workspace too small (%zu bytes)", ws_bytes);
@@ -1577,11 +1577,35 @@ int sde_conv_dgrad_bnbwd(const sde_conv_desc* d, const void* w_packed, void* gm,
     SDE_CHECK_ARG(kind != 0, "sde_conv_dgrad_bnbwd: this layer has no fused form (ask sde_conv_dgrad_bnbwd_rows first)");
     p.w = w_packed; p.bias = nullptr; p.y = gm; p.stats = part; p.Cout = Cout; p.ldy = ldy; p.act = SDE_ACT_NONE;
     p.ksplit = 1; p.ws = nullptr; p.no_kfull = 0;
-    p.bn_y = bn_y; p.bnp = bnp;
+    p.bn_y = bn_y; p.bnp = bnp; p.bn_gb = nullptr; p.bn_out = nullptr;
     if (kind == 1) sdeconv::pgemm_run(p, d->dtype, g_pgemm_depth, (hipStream_t)stream);
     else if (d->dtype == SDE_BF16) dispatch_halo<bf16_t>(p, (hipStream_t)stream);
     else dispatch_halo<half_t>(p, (hipStream_t)stream);
     SDE_CHECK_LAUNCH("sde_conv_dgrad_bnbwd");
+    return SDE_OK;
+}
+
+// The same for a BatchNorm followed by "+ identity, ReLU" whose output has a second consumer (torchvision's Bottleneck: conv1 of the next block and that
+// block's skip path): gm = (g + res_grad) * [bn_out > 0], partials of (sum gm, sum gm * xhat) -- the whole bn_bwd_reduce pass of the residual BatchNorm.
+// Only the persistent GEMM carries this form.
+int sde_conv_dgrad_bnbwd_res_rows(const sde_conv_desc* d, int Cout, int ldy) {
+    Gather g;
+    if (!d || fill_gather(d, g, "sde_conv_dgrad_bnbwd_res_rows") != SDE_OK) return 0;
+    return bnbwd_kind(g, d->dtype, ldy, Cout) == 1 ? sdeconv::pgemm_stats_rows(g, ldy, g_pgemm_depth, true) : 0;
+}
+
+int sde_conv_dgrad_bnbwd_res(const sde_conv_desc* d, const void* w_packed, void* gm, int Cout, int ldy, const void* bn_y, const float* bnp, float* part,
+                             const void* res_grad, const void* bn_out, sde_stream_t stream) {
+    SDE_CHECK_ARG(d && w_packed && gm && bn_y && bnp && part && res_grad && bn_out, "sde_conv_dgrad_bnbwd_res: null pointer");
+    IGemmP p;
+    int rc = fill_gather(d, p.g, "sde_conv_dgrad_bnbwd_res");
+    if (rc) return rc;
+    SDE_CHECK_ARG(bnbwd_kind(p.g, d->dtype, ldy, Cout) == 1, "sde_conv_dgrad_bnbwd_res: this layer has no fused form (ask sde_conv_dgrad_bnbwd_res_rows first)");
+    p.w = w_packed; p.bias = nullptr; p.y = gm; p.stats = part; p.Cout = Cout; p.ldy = ldy; p.act = SDE_ACT_NONE;
+    p.ksplit = 1; p.ws = nullptr; p.no_kfull = 0;
+    p.bn_y = bn_y; p.bnp = bnp; p.bn_gb = res_grad; p.bn_out = bn_out;
+    sdeconv::pgemm_run(p, d->dtype, g_pgemm_depth, (hipStream_t)stream);
+    SDE_CHECK_LAUNCH("sde_conv_dgrad_bnbwd_res");
     return SDE_OK;
 }
 

@@ -58,6 +58,10 @@ struct IGemmP {
     // `stats` slab in place of (sum y, sum y^2): the separate bn_bwd_reduce pass over g and y_bn disappears.
     const void* bn_y;     // [M][ldy] raw convolution output the BatchNorm normalised (same layout as this GEMM's output), or null
     const float* bnp;     // [4][Cout]: mean, rstd, scale, shift
+    // residual form (pgemm only): the BatchNorm is followed by "+ identity, ReLU" and its output has a second consumer whose gradient bn_gb arrives
+    // separately: the tile becomes (g + bn_gb) * [bn_out > 0] (the mask read from the block output instead of re-derived).  Both null otherwise.
+    const void* bn_gb;    // [M][ldy] gradient of the output's other consumer (the next block's skip path)
+    const void* bn_out;   // [M][ldy] relu(bn(bn_y) + identity): the mask
 };
 
 

@@ -491,37 +491,97 @@ __global__ void __launch_bounds__(64 * NW) pgemm_kernel(const PGemmP q) {
                 // makes its waitcnt pass track vector-memory events in this loop nest, and it then orders the K loop's LDS reads behind the
                 // LDS-DMA in flight (s_waitcnt vmcnt(0) per stage: the ring would run empty).  In-order vmcnt: waiting for these loads also
                 // waits for the (older) stages of the next tile already in flight, which the K loop would wait for next anyway.
+                // A register written by an asm load is "defined" for the compiler the moment that statement ends: it may copy it (live-range splits under
+                // pressure, joins of a branch) before the data has arrived.  So: no join between a load and its wait (each form below is straight-line and
+                // loads its own BatchNorm parameters), and the residual form -- 24 pending registers made the allocator split -- puts loads and wait
+                // into ONE statement, four rows at a time (operand limit).
                 const float* bp = p.bnp + cg;
-                pg_f32x2 mean, rstd, sc, sf;
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mean) : "v"(bp) : "memory");
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rstd) : "v"(bp + p.Cout) : "memory");
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sc) : "v"(bp + 2 * p.Cout) : "memory");
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sf) : "v"(bp + 3 * p.Cout) : "memory");
-                const unsigned char* yb = reinterpret_cast<const unsigned char*>(p.bn_y) + ((size_t)m0 * p.ldy + cg) * 2;
-                unsigned yraw[RPT];
-#pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    const int r = part + k * PARTS;
-                    const unsigned char* src = yb + (size_t)(r < rows ? r : 0) * p.ldy * 2;       // (rows >= 1; the value of an out-of-range row is not used)
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(yraw[k]) : "v"(src) : "memory");
-                }
-                static_assert(RPT == 8, "the wait below names eight loads");
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(mean), "+v"(rstd), "+v"(sc), "+v"(sf), "+v"(yraw[0]), "+v"(yraw[1]), "+v"(yraw[2]), "+v"(yraw[3]), "+v"(yraw[4]), "+v"(yraw[5]),
-                               "+v"(yraw[6]), "+v"(yraw[7])
-                             :: "memory");
+                const size_t tile_off = ((size_t)m0 * p.ldy + cg) * 2;
+                const unsigned char* yb = reinterpret_cast<const unsigned char*>(p.bn_y) + tile_off;
                 pg_f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+                static_assert(RPT == 8, "the waits below name eight rows");
+                if (p.bn_gb == nullptr) {
+                    pg_f32x2 mean, rstd, sc, sf;
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mean) : "v"(bp) : "memory");
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(rstd) : "v"(bp + p.Cout) : "memory");
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sc) : "v"(bp + 2 * p.Cout) : "memory");
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sf) : "v"(bp + 3 * p.Cout) : "memory");
+                    unsigned yraw[RPT];
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    const int r = part + k * PARTS;
-                    if (r < rows) {
-                        pg_f32x2 t = PgType<T16>::unpack2(*reinterpret_cast<const unsigned*>(sC + r * CST + c2 * 4));
-                        const pg_f32x2 yv = PgType<T16>::unpack2(yraw[k]);
-                        t[0] = fmaf(yv[0], sc[0], sf[0]) > 0.f ? t[0] : 0.f;
-                        t[1] = fmaf(yv[1], sc[1], sf[1]) > 0.f ? t[1] : 0.f;
-                        pg_lds_store4(sC_a + r * CST + c2 * 4, PgType<T16>::pack2(t[0], t[1]));
-                        s1 += t;
-                        s2 += t * ((yv - mean) * rstd);
+                    for (int k = 0; k < RPT; ++k) {
+                        const int r = part + k * PARTS;
+                        const unsigned char* src = yb + (size_t)(r < rows ? r : 0) * p.ldy * 2;       // (rows >= 1; the value of an out-of-range row is not used)
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(yraw[k]) : "v"(src) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(mean), "+v"(rstd), "+v"(sc), "+v"(sf), "+v"(yraw[0]), "+v"(yraw[1]), "+v"(yraw[2]), "+v"(yraw[3]), "+v"(yraw[4]), "+v"(yraw[5]),
+                                   "+v"(yraw[6]), "+v"(yraw[7])
+                                 :: "memory");
+#pragma unroll
+                    for (int k = 0; k < RPT; ++k) {
+                        const int r = part + k * PARTS;
+                        if (r < rows) {
+                            pg_f32x2 t = PgType<T16>::unpack2(*reinterpret_cast<const unsigned*>(sC + r * CST + c2 * 4));
+                            const pg_f32x2 yv = PgType<T16>::unpack2(yraw[k]);
+                            t[0] = fmaf(yv[0], sc[0], sf[0]) > 0.f ? t[0] : 0.f;
+                            t[1] = fmaf(yv[1], sc[1], sf[1]) > 0.f ? t[1] : 0.f;
+                            pg_lds_store4(sC_a + r * CST + c2 * 4, PgType<T16>::pack2(t[0], t[1]));
+                            s1 += t;
+                            s2 += t * ((yv - mean) * rstd);
+                        }
+                    }
+                } else {
+                    // residual form: g += the other consumer's gradient (bn_gb), mask read from the block output (bn_out)
+                    const unsigned char* gbb = reinterpret_cast<const unsigned char*>(p.bn_gb) + tile_off;
+                    const unsigned char* ob = reinterpret_cast<const unsigned char*>(p.bn_out) + tile_off;
+                    pg_f32x2 mean, rstd;
+#pragma unroll
+                    for (int h = 0; h < RPT; h += 4) {
+                        unsigned yr[4], gr[4], orr[4];
+                        size_t ro[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int r = part + (h + k) * PARTS;
+                            ro[k] = (size_t)(r < rows ? r : 0) * p.ldy * 2;
+                        }
+                        if (h == 0)
+                            asm volatile(
+                                "global_load_dwordx2 %12, %26, off\n\tglobal_load_dwordx2 %13, %27, off\n\t"
+                                "global_load_dword %0, %14, off\n\tglobal_load_dword %1, %15, off\n\tglobal_load_dword %2, %16, off\n\tglobal_load_dword %3, %17, off\n\t"
+                                "global_load_dword %4, %18, off\n\tglobal_load_dword %5, %19, off\n\tglobal_load_dword %6, %20, off\n\tglobal_load_dword %7, %21, off\n\t"
+                                "global_load_dword %8, %22, off\n\tglobal_load_dword %9, %23, off\n\tglobal_load_dword %10, %24, off\n\tglobal_load_dword %11, %25, off\n\t"
+                                "s_waitcnt vmcnt(0)"
+                                : "=&v"(yr[0]), "=&v"(yr[1]), "=&v"(yr[2]), "=&v"(yr[3]), "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2]), "=&v"(gr[3]),
+                                  "=&v"(orr[0]), "=&v"(orr[1]), "=&v"(orr[2]), "=&v"(orr[3]), "=&v"(mean), "=&v"(rstd)
+                                : "v"(yb + ro[0]), "v"(yb + ro[1]), "v"(yb + ro[2]), "v"(yb + ro[3]), "v"(gbb + ro[0]), "v"(gbb + ro[1]), "v"(gbb + ro[2]), "v"(gbb + ro[3]),
+                                  "v"(ob + ro[0]), "v"(ob + ro[1]), "v"(ob + ro[2]), "v"(ob + ro[3]), "v"(bp), "v"(bp + p.Cout)
+                                : "memory");
+                        else
+                            asm volatile(
+                                "global_load_dword %0, %12, off\n\tglobal_load_dword %1, %13, off\n\tglobal_load_dword %2, %14, off\n\tglobal_load_dword %3, %15, off\n\t"
+                                "global_load_dword %4, %16, off\n\tglobal_load_dword %5, %17, off\n\tglobal_load_dword %6, %18, off\n\tglobal_load_dword %7, %19, off\n\t"
+                                "global_load_dword %8, %20, off\n\tglobal_load_dword %9, %21, off\n\tglobal_load_dword %10, %22, off\n\tglobal_load_dword %11, %23, off\n\t"
+                                "s_waitcnt vmcnt(0)"
+                                : "=&v"(yr[0]), "=&v"(yr[1]), "=&v"(yr[2]), "=&v"(yr[3]), "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2]), "=&v"(gr[3]),
+                                  "=&v"(orr[0]), "=&v"(orr[1]), "=&v"(orr[2]), "=&v"(orr[3])
+                                : "v"(yb + ro[0]), "v"(yb + ro[1]), "v"(yb + ro[2]), "v"(yb + ro[3]), "v"(gbb + ro[0]), "v"(gbb + ro[1]), "v"(gbb + ro[2]), "v"(gbb + ro[3]),
+                                  "v"(ob + ro[0]), "v"(ob + ro[1]), "v"(ob + ro[2]), "v"(ob + ro[3])
+                                : "memory");
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int r = part + (h + k) * PARTS;
+                            if (r < rows) {
+                                pg_f32x2 t = PgType<T16>::unpack2(*reinterpret_cast<const unsigned*>(sC + r * CST + c2 * 4));
+                                const pg_f32x2 yv = PgType<T16>::unpack2(yr[k]), gv = PgType<T16>::unpack2(gr[k]), ov = PgType<T16>::unpack2(orr[k]);
+                                // (g + g_other) rounded to the storage type BEFORE the mask and the sums, exactly as bn_bwd_reduce forms gm
+                                const pg_f32x2 sum = PgType<T16>::unpack2(PgType<T16>::pack2(t[0] + gv[0], t[1] + gv[1]));
+                                t[0] = ov[0] > 0.f ? sum[0] : 0.f;
+                                t[1] = ov[1] > 0.f ? sum[1] : 0.f;
+                                pg_lds_store4(sC_a + r * CST + c2 * 4, PgType<T16>::pack2(t[0], t[1]));
+                                s1 += t;
+                                s2 += t * ((yv - mean) * rstd);
+                            }
+                        }
                     }
                 }
                 if (q.stats_acc) { st1[ch] += s1; st2[ch] += s2; st_n0 = n0; }

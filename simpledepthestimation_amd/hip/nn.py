@@ -35,6 +35,8 @@ L.register_protos({
     "sde_conv_fwd_variant": ([POINTER(ConvDesc), _I], c_int),
     "sde_conv_dgrad_bnbwd_rows": ([POINTER(ConvDesc), _I, _I], c_int),
     "sde_conv_dgrad_bnbwd": ([POINTER(ConvDesc), _P, _P, _I, _I, _P, _P, _P, _P], c_int),
+    "sde_conv_dgrad_bnbwd_res_rows": ([POINTER(ConvDesc), _I, _I], c_int),
+    "sde_conv_dgrad_bnbwd_res": ([POINTER(ConvDesc), _P, _P, _I, _I, _P, _P, _P, _P, _P, _P], c_int),
     "sde_bn_bwd_from_part": ([_P, _I, _P, _P, _P, _LG, _I, _I, _P, _P, _P, _I, _P, _P], c_int),
     "sde_conv_set_halo_min_blocks": ([_I], c_int),
     "sde_conv_set_option": ([_I, _I], c_int),
@@ -220,6 +222,10 @@ class _Conv2d(torch.autograd.Function):
         # x0 = relu(BatchNorm(y_bn)) with this convolution as its only consumer: the data gradient below can carry BatchNorm's backward reduction
         ent = _BN_OUT.pop(x0.data_ptr(), None) if _BN_OUT else None
         ctx.bn_in = (ent[1], ent[2]) if (ent is not None and ent[0]() is x0 and x1 is None and not upcat and not reflect and stride == 1) else None
+        # x0 = relu(BatchNorm(y_bn) + identity) with this convolution and the next block's skip path as its two consumers: the data gradient below can take over
+        # that BatchNorm's whole backward reduce pass, once the skip path's gradient has arrived (_RES_GRAD)
+        entr = _BN_OUT_RES.get(x0.data_ptr()) if (_BN_OUT_RES and RESBN_FUSED) else None
+        ctx.bn_in_res = (entr[1], entr[2]) if (entr is not None and entr[0]() is x0 and x1 is None and not upcat and not reflect and stride == 1 and ctx.bn_in is None) else None
         y, stats = conv_raw(d, dt, wp, b32, act, Cout, ldy, want_stats, x0.device, "igemm_fwd", flops)
         ctx.save_for_backward(x0, x1, weight, y if act != ACT_NONE else None)
         ctx.params = (weight, bias)
@@ -418,6 +424,28 @@ class _Conv2d(torch.autograd.Function):
                         raise L.SdeHipError("upsample+concat source is only supported with reflection padding (decoder)")
                     if stride == 1:
                         dd = _desc(dz, None, SRC_PLAIN, KH, KW, 1, KH - 1 - pad, False, OH, OW, IH, IW)
+                        g_other = _RES_GRAD.pop(x0.data_ptr(), None) if (ctx.bn_in_res is not None and _RES_GRAD) else None
+                        if g_other is not None and not (g_other.shape == x0.shape and g_other.dtype == dt and g_other.is_contiguous()):
+                            g_other = None
+                        rows = lib.sde_conv_dgrad_bnbwd_res_rows(ctypes.byref(dd), Cv, Cv) if g_other is not None else 0
+                        if rows > 0:
+                            # gm = (this data gradient + the skip path's gradient) * relu'(x0), with the partials of the BatchNorm behind x0: that BatchNorm's
+                            # backward finds both under the gradient's address, skips its reduce pass and does not add the skip gradient again
+                            y_bn, bnp = ctx.bn_in_res
+                            part = torch.empty(rows + REDUCE_ROWS, Cv, 2, device=dev, dtype=torch.float32)
+                            dx0 = torch.empty(B, IH, IW, Cv, device=dev, dtype=dt)
+                            variant = lib.sde_conv_fwd_variant(ctypes.byref(dd), Cv) if L.PROFILE is not None else 0
+                            meta = dict(M=B * IH * IW, N=Cv, K=KH * KW * ldy, k=KH, s=1, mode=0, bytes=2 * (dz.numel() + 4 * dx0.numel())) if L.PROFILE is not None else None
+                            _timed("igemm_dgrad", flops, variant, lambda: L.check(lib.sde_conv_dgrad_bnbwd_res(ctypes.byref(dd), L.ptr(wd), L.ptr(dx0), Cv, Cv, L.ptr(y_bn),
+                                                                                                           L.ptr(bnp), L.ptr(part), L.ptr(g_other), L.ptr(x0), L.stream()),
+                                                                                  "sde_conv_dgrad_bnbwd_res"), meta)
+                            if len(_BN_PART) > 16:
+                                _BN_PART.clear()
+                            _BN_PART[dx0.data_ptr()] = (y_bn.data_ptr(), part, rows, g_other.data_ptr())
+                            st["dx0"], st["dx1"] = dx0, None
+                            return
+                        if g_other is not None:
+                            _RES_GRAD[x0.data_ptr()] = g_other                # (no fused form for this layer after all: nothing consumed)
                         rows = lib.sde_conv_dgrad_bnbwd_rows(ctypes.byref(dd), Cv, Cv) if (ctx.bn_in is not None and BNBWD_FUSED) else 0
                         if rows > 0:
                             # the GEMM's epilogue masks the gradient with relu'(bn(y_bn)) and leaves BatchNorm's (sum gm, sum gm * xhat) partials:
@@ -570,6 +598,10 @@ class WGradReducer:
 FUSE_BN_FINALIZE = True  # BatchNorm finalize + apply in one launch where the partial slab is short (A/B: set False)
 BNBWD_FUSED = True      # BatchNorm's backward reduce pass in the epilogue of the data-gradient GEMM that produces its incoming gradient (A/B, tests: False)
 BNBWD_HITS = 0          # times the fused path ran (tests)
+RESBN_FUSED = os.environ.get("SDE_RESBN", "1") != "0"      # ... and the whole reduce pass of a residual BatchNorm in the data gradient of the next block's first convolution (A/B, tests: False)
+RESBN_HITS = 0
+_BN_OUT_RES = {}        # data_ptr of a residual BatchNorm+ReLU output with two consumers -> (weakref to it, y, bnp)
+_RES_GRAD = {}          # data_ptr of a block input -> the gradient that arrived over the block's skip path (set by the block's last BatchNorm backward)
 _BN_OUT = {}            # data_ptr of a residual-free BatchNorm+ReLU output -> (weakref to it, y, bnp): set by _BatchNormAct.forward, taken by _Conv2d.forward
 _BN_PART = {}           # data_ptr of the masked gradient a fused data-gradient GEMM returned -> (y.data_ptr(), partial slab, rows)
 WGRAD_DEFER = None      # HipTrainer installs a WGradReducer around backward
@@ -685,6 +717,14 @@ class _BatchNormAct(torch.autograd.Function):
                 _BN_OUT.clear()
             _BN_PART.clear()                          # (entries live from a convolution's backward to this BatchNorm's backward only)
             _BN_OUT[out.data_ptr()] = (weakref.ref(out), y, bnp)
+        ctx.res_ptr = residual.data_ptr() if residual is not None else None
+        if training and relu and residual is not None and n_out == 2 and dt != torch.float32 and C % 64 == 0 and ctx.needs_input_grad[0] and BNBWD_FUSED and RESBN_FUSED:
+            # residual BatchNorm + ReLU with two consumers (torchvision's blocks: the next block's first convolution and its skip path): that convolution's
+            # data gradient can carry this BatchNorm's backward reduce pass (residual form), see _Conv2d.backward
+            if len(_BN_OUT_RES) > 64:
+                _BN_OUT_RES.clear()
+            _RES_GRAD.clear()                         # (entries live from a block's last BatchNorm backward to its first convolution's backward only)
+            _BN_OUT_RES[out.data_ptr()] = (weakref.ref(out), y, bnp)
         if n_out == 1:
             return out
         return (out,) + tuple(out.view(out.shape) for _ in range(n_out - 1))
@@ -724,6 +764,23 @@ class _BatchNormAct(torch.autograd.Function):
             if direct:
                 dgamma = dbeta = None
             return dy, None, dgamma, dbeta, None, None, None, None, None, None, None, None
+        entr = _BN_PART.get(grads[0].data_ptr()) if (_BN_PART and len(grads) == 2 and relu and has_res) else None
+        if entr is not None and len(entr) == 4:
+            # residual form: the next block's first convolution already formed gm = (its data gradient + the skip gradient) * relu'(out) and reduced it
+            del _BN_PART[grads[0].data_ptr()]
+            if not (entr[0] == y.data_ptr() and entr[3] == grads[1].data_ptr() and grads[0].shape == y.shape and grads[0].dtype == dt):
+                raise L.SdeHipError("BatchNorm backward: a data gradient that already contains the skip path's gradient arrived at a BatchNorm it was not "
+                                    "formed for (hip.nn.RESBN_FUSED = False selects the separate reduce pass)")
+            global RESBN_HITS
+            RESBN_HITS += 1
+            gm = grads[0]
+            L.check(lib.sde_bn_bwd_from_part(L.ptr(entr[1]), entr[2], L.ptr(gm), L.ptr(y), L.ptr(bnp), M, C, dtype_code(dt), L.ptr(coef), L.ptr(dgamma),
+                                             L.ptr(dbeta), int(direct), L.ptr(dy), L.stream()), "sde_bn_bwd_from_part")
+            if ctx.res_ptr is not None:
+                _RES_GRAD[ctx.res_ptr] = gm
+            if direct:
+                dgamma = dbeta = None
+            return dy, None, dgamma, dbeta, None, None, gm, None, None, None, None, None
         part = torch.empty(lib.sde_reduce_num_blocks(M, C) + REDUCE_ROWS, C, 2, device=dev)
         # gm = relu'(out) * (sum of the incoming gradients): needed when there is anything to mask or to sum; it is also the residual's gradient
         gm = torch.empty_like(y) if (relu or len(grads) > 1) else None
@@ -731,6 +788,8 @@ class _BatchNormAct(torch.autograd.Function):
         L.check(lib.sde_bn_bwd(L.ptr(d0), L.ptr(d1), L.ptr(d2), L.ptr(out), L.ptr(y), L.ptr(bnp), L.ptr(gamma), int(relu), M, C, dtype_code(dt), L.ptr(part),
                                L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta), int(direct), L.ptr(gm), L.ptr(dy), L.stream()), "sde_bn_bwd")
         dres = (gm if gm is not None else d0) if has_res else None
+        if dres is not None and ctx.res_ptr is not None and RESBN_FUSED and _BN_OUT_RES:
+            _RES_GRAD[ctx.res_ptr] = dres          # the skip path's gradient, for the data gradient of the convolution that shares the block input (residual form)
         if direct:
             dgamma = dbeta = None
         return dy, None, dgamma, dbeta, None, None, dres, None, None, None, None, None

@@ -705,3 +705,32 @@ def test_fp16_loss_scaling_steps_track_fp32_and_overflow_skips_the_step(arch, en
     # Adam's `step` counts the APPLIED updates only (GradScaler.step skips optimizer.step() on overflow), not the calls
     assert t16.applied_steps() == sum(moved) and t16.t == len(moved) + 1
     assert all(float(e["step"]) == sum(moved) for e in osd["state"].values())
+
+
+def test_residual_batchnorm_backward_rides_in_the_next_blocks_data_gradient():
+    """torchvision's Bottleneck (resnet_encoder.py:L88-99): out = relu(bn3(y) + identity) feeds conv1 of the next block and its skip path.  The residual form of
+    sde_conv_dgrad_bnbwd lets that conv1's data gradient do bn3's whole backward reduce pass (12 of ResNet-50's 16 blocks): same losses, same gradients as the
+    separate pass (the sums are formed from the same rounded gm values, in another order)."""
+    from simpledepthestimation_amd.hip import nn as HN
+    sd = OM.init_state_dict(50, seed=5)
+    batch = {k: v.to(dev) for k, v in sup_batch(2, 64, 192, 31).items()}
+    res = []
+    for fused in (False, True):
+        kept, HN.RESBN_FUSED = HN.RESBN_FUSED, fused
+        hits = HN.RESBN_HITS
+        try:
+            model = build("SupDepthModel", 50, sd, "bf16").train()
+            out = model(clone_batch(batch))
+            out["silog_loss"].backward()
+            torch.cuda.synchronize()
+        finally:
+            HN.RESBN_FUSED = kept
+        assert (HN.RESBN_HITS - hits) == (12 if fused else 0), HN.RESBN_HITS - hits
+        res.append((float(out["silog_loss"]), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert res[0][0] == res[1][0]
+    # bf16 storage: the two paths round the same values in another order, and 50 BatchNorm'd layers amplify that towards the stem (its BatchNorm bias, a sum
+    # with cancellation, moves most); the op-level test (test_gpu_nn.py) holds the kernel itself to 1e-5
+    worst = max((rel(res[1][1][n], res[0][1][n]), n) for n in res[0][1])
+    assert worst[0] < 6e-2, worst
+    a = torch.cat([res[1][1][n].flatten().double() for n in res[0][1]]); b = torch.cat([res[0][1][n].flatten().double() for n in res[0][1]])
+    assert float((a - b).norm() / b.norm()) < 3e-2          # (measured 1.1e-2: bf16 re-rounding noise of 16 blocks; the bf16-vs-fp32 test bounds both paths)

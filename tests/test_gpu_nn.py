@@ -953,3 +953,42 @@ def test_persistent_kernels_with_a_cu_reserve(NN, reserve):
         assert float((a - b).abs().max()) <= tol, (name, float((a - b).abs().max()), tol)
     with pytest.raises(Exception):
         NN.set_option(NN.OPT_CU_RESERVE, 12)
+
+
+@pytest.mark.parametrize("case", [("k64_single_stage", 2, 24, 40, 256, 64, 1), ("k128", 2, 12, 20, 512, 128, 1), ("3x3", 4, 24, 40, 128, 128, 3),
+                                  ("many_tiles", 12, 48, 160, 256, 64, 1), ("ragged_rows", 1, 7, 9, 256, 64, 1)], ids=lambda c: c[0])
+def test_residual_batchnorm_backward_in_the_data_gradient(NN, case):
+    """Residual form of the fused BatchNorm backward (sde_conv_dgrad_bnbwd_res): block input u = relu(bn_a(y_a) + r) feeds the next block's first convolution
+    and its skip path; that convolution's data gradient forms gm = (g + skip gradient) * relu'(u) and bn_a's partial sums.  Against the separate reduce pass."""
+    name, B, H, W, C, C2, k = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(B * 100 + C + k)
+    x = (torch.randn(B, 64, H, W, generator=g) + 0.2).to(dt).float()
+    r = (torch.randn(B, C, H, W, generator=g) * 0.5).to(dt).float()
+    wa = (torch.randn(C, 64, 1, 1, generator=g) / 8).to(dt).float()
+    w1 = (torch.randn(C2, C, k, k, generator=g) / math.sqrt(C * k * k)).to(dt).float()
+    w3 = (torch.randn(C, C2, 1, 1, generator=g) / math.sqrt(C2)).to(dt).float()
+    ga, ba, gb, bb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    go = torch.randn(B, C, H, W, generator=g).to(dt).float()
+    res = []
+    for fused in (False, True):
+        kept, NN.RESBN_FUSED = NN.RESBN_FUSED, fused
+        try:
+            xd, rd = nhwc(x, dt, 8).requires_grad_(True), nhwc(r, dt, 8).requires_grad_(True)
+            wad, w1d, w3d, gad, bad, gbd, bbd = (t.clone().to(dev).requires_grad_(True) for t in (wa, w1, w3, ga, ba, gb, bb))
+            hits = NN.RESBN_HITS
+            ya, sa = NN.conv2d(xd, wad, None, stride=1, pad=0, bn_stats=True)
+            ua, ub = NN.batch_norm_act(ya, sa, gad, bad, torch.zeros(C, device=dev), torch.ones(C, device=dev), residual=rd, relu=True, n_out=2)
+            h = NN.conv2d(ua, w1d, None, stride=1, pad=k // 2)
+            y3, s3 = NN.conv2d(h, w3d, None, stride=1, pad=0, bn_stats=True)
+            out = NN.batch_norm_act(y3, s3, gbd, bbd, torch.zeros(C, device=dev), torch.ones(C, device=dev), residual=ub, relu=True)
+            out.backward(nhwc(go, dt, 8))
+            torch.cuda.synchronize()
+            took = NN.RESBN_HITS - hits          # (3x3: only where the dispatcher runs this layer on the persistent GEMM; the results must agree either way)
+            assert took == (1 if fused else 0) or (name == "3x3" and took == 0), f"{name}: residual form {'not ' if fused else ''}taken"
+            res.append([t.detach().float().cpu() for t in (out, xd.grad, rd.grad, wad.grad, w1d.grad, w3d.grad, gad.grad, bad.grad, gbd.grad, bbd.grad)])
+        finally:
+            NN.RESBN_FUSED = kept
+    for nm, u, f in zip(("out", "dX", "dR", "dWa", "dW1", "dW3", "dgamma_a", "dbeta_a", "dgamma_b", "dbeta_b"), res[0], res[1]):
+        assert torch.isfinite(f).all(), f"{name} {nm}: not finite"
+        assert relerr(f, u) < (1e-6 if nm in ("out", "dW3", "dgamma_b", "dbeta_b", "dW1") else 3e-3), f"{name} {nm}: fused vs separate {relerr(f, u):.3e}"
