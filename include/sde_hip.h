@@ -229,7 +229,8 @@ int sde_conv_dgrad_bnbwd(const sde_conv_desc* d, const void* w_packed, void* gm,
                          sde_stream_t stream);
 /* The residual form (torchvision Bottleneck, resnet_encoder.py:L88-99: out = relu(bn3(y_bn) + identity) feeds conv1 of the next block AND that block's
  * skip path): the data gradient of that conv1 takes over the WHOLE reduce pass of bn3's backward -- gm = (g + res_grad) * (bn_out > 0), res_grad the
- * gradient arriving over the skip path, bn_out the block output (the mask), and the same partial slab.  Persistent GEMM only (rows = 0 otherwise). */
+ * gradient arriving over the skip path, bn_out the block output (the mask), and the same partial slab.  Persistent GEMM and LDS-halo 3x3 kernel
+ * (BasicBlock: bn2 -> conv1 of the next block); rows = 0 where neither runs the layer. */
 int sde_conv_dgrad_bnbwd_res_rows(const sde_conv_desc* d, int Cout, int ldy);
 int sde_conv_dgrad_bnbwd_res(const sde_conv_desc* d, const void* w_packed, void* gm, int Cout, int ldy, const void* bn_y, const float* bnp, float* part,
                              const void* res_grad, const void* bn_out, sde_stream_t stream);

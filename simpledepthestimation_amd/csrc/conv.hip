@@ -674,12 +674,28 @@ __global__ void __launch_bounds__(NTHREADS, 2) halo3_kernel(IGemmP p) {
             const float4 q = *reinterpret_cast<const float4*>(&sC[row * (BN + CPAD) + c0]);
             const float v[4] = {q.x, q.y, q.z, q.w};
             T o[4];
+            if (p.bn_gb) {
+                // residual form (IGemmP::bn_gb / bn_out): gm = (g + the other consumer's gradient) * [block output > 0], each sum rounded to the storage
+                // type where bn_bwd_reduce would have read it from memory
+                const uint2 gr = *reinterpret_cast<const uint2*>((const T*)p.bn_gb + off), orr = *reinterpret_cast<const uint2*>((const T*)p.bn_out + off);
+                const T* gt = reinterpret_cast<const T*>(&gr);
+                const T* ot = reinterpret_cast<const T*>(&orr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yv = to_f32<T>(yt[e]);
+                    const float ga = to_f32<T>(from_f32<T>(v[e]));
+                    o[e] = from_f32<T>(to_f32<T>(ot[e]) > 0.f ? ga + to_f32<T>(gt[e]) : 0.f);
+                    const float t = to_f32<T>(o[e]);
+                    a1[e] += t; a2[e] += t * ((yv - mn[e]) * rs[e]);
+                }
+            } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float yv = to_f32<T>(yt[e]);
                 o[e] = from_f32<T>(fmaf(yv, sc[e], sf[e]) > 0.f ? v[e] : 0.f);
                 const float t = to_f32<T>(o[e]);
                 a1[e] += t; a2[e] += t * ((yv - mn[e]) * rs[e]);
+            }
             }
             *reinterpret_cast<uint2*>((T*)p.y + off) = *reinterpret_cast<uint2*>(o);
         }
@@ -1587,11 +1603,12 @@ int sde_conv_dgrad_bnbwd(const sde_conv_desc* d, const void* w_packed, void* gm,
 
 // The same for a BatchNorm followed by "+ identity, ReLU" whose output has a second consumer (torchvision's Bottleneck: conv1 of the next block and that
 // block's skip path): gm = (g + res_grad) * [bn_out > 0], partials of (sum gm, sum gm * xhat) -- the whole bn_bwd_reduce pass of the residual BatchNorm.
-// Only the persistent GEMM carries this form.
+// The persistent GEMM and the LDS-halo 3x3 kernel (BasicBlock's conv1) carry this form.
 int sde_conv_dgrad_bnbwd_res_rows(const sde_conv_desc* d, int Cout, int ldy) {
     Gather g;
     if (!d || fill_gather(d, g, "sde_conv_dgrad_bnbwd_res_rows") != SDE_OK) return 0;
-    return bnbwd_kind(g, d->dtype, ldy, Cout) == 1 ? sdeconv::pgemm_stats_rows(g, ldy, g_pgemm_depth, true) : 0;
+    const int kind = bnbwd_kind(g, d->dtype, ldy, Cout);
+    return kind == 1 ? sdeconv::pgemm_stats_rows(g, ldy, g_pgemm_depth, true) : kind == 2 ? halo_tiles_m(g) : 0;
 }
 
 int sde_conv_dgrad_bnbwd_res(const sde_conv_desc* d, const void* w_packed, void* gm, int Cout, int ldy, const void* bn_y, const float* bnp, float* part,
@@ -1600,11 +1617,14 @@ int sde_conv_dgrad_bnbwd_res(const sde_conv_desc* d, const void* w_packed, void*
     IGemmP p;
     int rc = fill_gather(d, p.g, "sde_conv_dgrad_bnbwd_res");
     if (rc) return rc;
-    SDE_CHECK_ARG(bnbwd_kind(p.g, d->dtype, ldy, Cout) == 1, "sde_conv_dgrad_bnbwd_res: this layer has no fused form (ask sde_conv_dgrad_bnbwd_res_rows first)");
+    const int kind = bnbwd_kind(p.g, d->dtype, ldy, Cout);
+    SDE_CHECK_ARG(kind != 0, "sde_conv_dgrad_bnbwd_res: this layer has no fused form (ask sde_conv_dgrad_bnbwd_res_rows first)");
     p.w = w_packed; p.bias = nullptr; p.y = gm; p.stats = part; p.Cout = Cout; p.ldy = ldy; p.act = SDE_ACT_NONE;
     p.ksplit = 1; p.ws = nullptr; p.no_kfull = 0;
     p.bn_y = bn_y; p.bnp = bnp; p.bn_gb = res_grad; p.bn_out = bn_out;
-    sdeconv::pgemm_run(p, d->dtype, g_pgemm_depth, (hipStream_t)stream);
+    if (kind == 1) sdeconv::pgemm_run(p, d->dtype, g_pgemm_depth, (hipStream_t)stream);
+    else if (d->dtype == SDE_BF16) dispatch_halo<bf16_t>(p, (hipStream_t)stream);
+    else dispatch_halo<half_t>(p, (hipStream_t)stream);
     SDE_CHECK_LAUNCH("sde_conv_dgrad_bnbwd_res");
     return SDE_OK;
 }
