@@ -312,6 +312,7 @@ class HipTrainer:
         finally:
             HN.WGRAD_DEFER = None
             HN.MAIN_STREAM = None
+            HN._RES_GRAD.clear(); HN._BN_PART.clear()      # hand-over entries between backward nodes: nothing outlives the phase
             L.join_aux()            # (backward raised before the join above)
             if self._wreduce is not None:
                 self._wreduce.join_pending()

@@ -725,6 +725,7 @@ class _BatchNormAct(torch.autograd.Function):
                 _BN_OUT_RES.clear()
             _RES_GRAD.clear()                         # (entries live from a block's last BatchNorm backward to its first convolution's backward only)
             _BN_OUT_RES[out.data_ptr()] = (weakref.ref(out), y, bnp)
+            ctx.res_tag = out.data_ptr()              # (this BatchNorm's backward drops the entry: the consuming convolution took its references in forward)
         if n_out == 1:
             return out
         return (out,) + tuple(out.view(out.shape) for _ in range(n_out - 1))
@@ -733,6 +734,8 @@ class _BatchNormAct(torch.autograd.Function):
     def backward(ctx, *douts):
         y, out, bnp, gamma = ctx.saved_tensors
         relu, has_res, training = ctx.cfg
+        if getattr(ctx, "res_tag", None) is not None:
+            _BN_OUT_RES.pop(ctx.res_tag, None)
         if not training:
             raise L.SdeHipError("BatchNorm backward in eval mode is not on the path")
         grads = [d.contiguous() for d in douts if d is not None]
