@@ -428,6 +428,8 @@ def main():
                 HN.BIAS_DEFER = bool(int(v))
             elif k == "resbn":                  # --opt resbn=0 -> residual BatchNorms keep their own backward reduce pass (A/B)
                 HN.RESBN_FUSED = bool(int(v))
+            elif k == "early_tail":             # --opt early_tail=0 -> the last weight-gradient group waits for the phase's flush (A/B)
+                HN.EARLY_TAIL = bool(int(v))
             elif k == "head_bias":              # --opt head_bias=0 -> disparity-head bias gradients by the separate pass
                 HN.HEAD_BIAS_FUSED = bool(int(v))
             else:

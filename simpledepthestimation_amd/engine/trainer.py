@@ -291,6 +291,8 @@ class HipTrainer:
         # convolution's backward must run on the stream this phase started on
         HN.MAIN_STREAM = torch.cuda.current_stream() if self.device.type == "cuda" else None
         tag = "" if self._cut is None else ("A_" if first_of_two else "B_")       # (marker names per phase of a two-phase backward)
+        if self._wreduce is not None:
+            self._wreduce.first_group = L.FIRST_GROUP_B if (self._cut is not None and not first_of_two) else None
         try:
             L.mark(tag + "bwd_start")
             run()

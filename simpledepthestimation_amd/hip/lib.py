@@ -153,6 +153,8 @@ def apply_schedule(family):
     global JOIN_LAG, WGRAD_GROUP, FIRST_GROUP
     if not SCHEDULE_LOCKED:
         JOIN_LAG, WGRAD_GROUP, FIRST_GROUP = SCHEDULES[family]
+FIRST_GROUP_B = None            # first-group digits of the SECOND phase of a two-phase (data-parallel) backward; None = FIRST_GROUP.  The group boundaries decide
+                                # how much weight-gradient work is left behind the phase's last data-gradient layer (its exposed tail)
 FIRST_GROUP = 0                 # sizes of the first groups of a backward phase as decimal digits (3: the first group has 3 layers; 33: the first two), 0: none;
                                 # set per network family (SCHEDULES)
 GROUP_MAX_BYTES = 128 << 20     # layers with more operand bytes fork alone (PackNet's 190 MB maps: 57.7 vs 60.2 ms/step)

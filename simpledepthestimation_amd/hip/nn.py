@@ -314,6 +314,10 @@ class _Conv2d(torch.autograd.Function):
             forked = False
             side = None
             if ctx.needs_input_grad[2]:
+                if not need_dx and WGRAD_DEFER is not None and WGRAD_DEFER.queue and not off_main and EARLY_TAIL:
+                    # a layer without a data gradient (the stem) ends the chain: its weight gradient runs on the main stream, so the group still queued goes
+                    # to the side stream NOW, underneath it, instead of after it at the phase's flush
+                    WGRAD_DEFER.run_queue()
                 d = _desc(x0, x1, SRC_UPCAT if upcat else SRC_PLAIN, KH, KW, stride, pad, reflect, IH, IW, OH, OW)
                 splits = lib.sde_conv_wgrad_splits(ctypes.byref(d), Cout)
                 wslot = _grad_slot(ctx.params[0])
@@ -378,7 +382,8 @@ class _Conv2d(torch.autograd.Function):
                     WGRAD_DEFER.queue.append((launch, (dz, x0, x1, slab, dw)))
                     WGRAD_DEFER.queue_bytes += op_bytes
                     # a group closes after WGRAD_GROUP layers or once its operands (kept alive until the group's GEMMs ran) exceed the byte budget
-                    prefix = str(L.FIRST_GROUP) if L.FIRST_GROUP else ""      # decimal digits = sizes of the first groups of the phase (33: 3 then 3)
+                    fg = WGRAD_DEFER.first_group if WGRAD_DEFER.first_group is not None else L.FIRST_GROUP      # (the second phase of a two-phase backward has its own)
+                    prefix = str(fg) if fg else ""      # decimal digits = sizes of the first groups of the phase (33: 3 then 3)
                     limit = int(prefix[WGRAD_DEFER.groups_done]) if WGRAD_DEFER.groups_done < len(prefix) else L.WGRAD_GROUP
                     if len(WGRAD_DEFER.queue) >= limit or WGRAD_DEFER.queue_bytes >= L.GROUP_BUDGET_BYTES:
                         WGRAD_DEFER.run_queue()
@@ -492,6 +497,7 @@ def _wptr(t):
     return c_void_p(t.data_ptr())
 
 
+EARLY_TAIL = True       # the last queued weight-gradient group is forked when the chain reaches a layer without a data gradient (A/B: False = at the flush)
 BIAS_DEFER = True       # bias-gradient column sums of a backward phase in one launch at its end (False: one finalize launch per layer, on the chain)
 
 
@@ -520,6 +526,7 @@ class WGradReducer:
         self.queue = []            # SDE_WGRAD_GROUP > 1: (launch closure, operands) of layers whose weight-gradient GEMM waits for its group's fork
         self.queue_bytes = 0       # operand bytes held by the queued layers
         self.groups_done = 0       # groups forked so far in this backward phase (the first one may be shorter: hip.lib.FIRST_GROUP)
+        self.first_group = None    # this phase's first-group digits when they differ from hip.lib.FIRST_GROUP (HipTrainer: second phase of a two-phase backward)
 
     def run_queue(self):
         """SDE_WGRAD_GROUP > 1: launch the queued weight-gradient GEMMs of the last few layers behind ONE fork of the side stream (one
