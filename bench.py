@@ -434,6 +434,8 @@ def main():
                 HN.HEAD_BIAS_FUSED = bool(int(v))
             else:
                 HN.set_option(int(k), int(v))
+                if int(k) == HN.OPT_WGRAD_BLOCKS:
+                    L.WGRAD_BLOCKS_LOCKED = True
         if args.no_side_stream:
             L.SIDE_STREAM = False
         if args.no_pgemm:

@@ -77,7 +77,10 @@ class HipTrainer:
                  adam_fn=None, overlap=None, late_from=("layer3",), cut_owner=None, amp=False, init_scale=65536.0, growth_interval=2000, pose_stream=True, cu_reserve=None):
         self.model = model
         kinds = {type(m).__name__ for m in model.modules()}
-        L.apply_schedule("packnet" if "PackNet01" in kinds else "resnet" if ("Bottleneck" in kinds or "BasicBlock" not in kinds) else "resnet_basic")
+        family = "packnet" if "PackNet01" in kinds else "resnet" if ("Bottleneck" in kinds or "BasicBlock" not in kinds) else "resnet_basic"
+        L.apply_schedule(family)
+        if not L.WGRAD_BLOCKS_LOCKED and next(model.parameters()).device.type == "cuda":
+            HN.set_option(HN.OPT_WGRAD_BLOCKS, L.WGRAD_BLOCKS[family])
         self._adam_fn = adam_fn or HN.adam_step      # tests on CPU (gloo) substitute a torch restatement of the same update
         self.adamw, self.betas, self.eps = bool(adamw), betas, float(eps)
         self.use_graph = bool(use_graph)

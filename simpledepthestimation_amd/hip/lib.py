@@ -146,6 +146,11 @@ WGRAD_GROUP = 6         # weight-gradient GEMMs of that many consecutive layers 
 #   bottleneck ResNets 0 (= 6) 6.77 against 6.89-6.94 ms/step for 1 / 2 / 3 / 4 / 5 / 7 / 8 / 9 (Supervised-R50), MonoDepth2-R50 8.06 vs 8.09 at 3;
 #   basic-block ResNets 3: Supervised-R18 3.50 -> 3.42, MonoDepth2-R18 4.69 -> 4.60 (2: 4.62, 4: 4.74, 5: 4.66).
 SCHEDULES = {"resnet": (1, 6, 0), "resnet_basic": (1, 6, 3), "packnet": (2, 3, 0)}
+# ... and the workgroup target of the weight-gradient GEMMs' pixel splits (SDE_OPT_WGRAD_BLOCKS).  Round 3, one call: ResNet-50 256 / 384 / 512 / 768 -> 6.37 / 6.45 /
+# 6.50 / 6.64 ms/step; PackNet-1A (weight gradients over 1.47 M pixels with 64 ... 512 channels) 256 / 512 / 768 / 1024 / 1536 / 2048 / 4096 -> 50.7-51.4 / 48.8 /
+# 48.4 / 47.9-48.0 / 48.1 / 48.6 / 50.5 (profiles/r03ah_packnet_sweep.txt)
+WGRAD_BLOCKS = {"resnet": 256, "resnet_basic": 256, "packnet": 1024}
+WGRAD_BLOCKS_LOCKED = False      # bench.py --opt 6=... pins the value for an A/B run
 SCHEDULE_LOCKED = False  # bench.py --const JOIN_LAG=... / WGRAD_GROUP=... pins the values for an A/B run
 
 
