@@ -1663,7 +1663,8 @@ int sde_conv_wgrad_splits(const sde_conv_desc* d, int Cout) {
     // a network's first layer (image input: <= 16 padded channels, huge M, a handful of output tiles) has no data gradient beside it and runs last
     // in backward with nothing else on the GPU: two workgroups per CU hide its gather latency (7x7 stem: 74 -> 51 us; the one-per-CU default is
     // the better choice only where the GEMM shares the GPU with the data-gradient chain)
-    if (d->C0 + d->C1 <= 16 && M >= 65536 && tiles <= 8) tgt *= 2;
+    // (a fixed target, not a multiple of the option: with PackNet's 1024 the 5x5 first layer ran 2048 workgroups and took 1.9 ms instead of 0.3)
+    if (d->C0 + d->C1 <= 16 && M >= 65536 && tiles <= 8) tgt = 2 * sdeconv::sde_persistent_cus();
     long want = (tgt + tiles - 1) / tiles;                  // default 256 (one workgroup per CU): measured best end to end -- every extra split is another fp32 slab through HBM
     const long max_by_rows = (M + 4 * BR - 1) / (4 * BR);   // at least 4 stages per split
     if (want > max_by_rows) want = max_by_rows;
