@@ -3,6 +3,5 @@ mk() { timeout -k 10 120 python bench.py --no-cpu-baseline --profile-steps 0 --s
 {
 echo "sup_r50 plain: $(mk --workload sup_r50)"
 echo "sup_r50 force-overlap: $(mk --workload sup_r50 --force-overlap)"
-echo "sup_r50 force-overlap not carried: $(mk --workload sup_r50 --force-overlap --opt carry=0)"
 } > gpurun_out/r03ac_marks.txt 2>&1
 cat gpurun_out/r03ac_marks.txt; tail -2 gpurun_out/marks.err

@@ -5,7 +5,7 @@ if [ $rc -ne 0 ]; then grep -E "Error|error|assert|FAILED" gpurun_out/r03ad_test
 one() { timeout -k 10 120 python bench.py --no-cpu-baseline --profile-steps 0 --steps 60 --warmup 10 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
 {
 for wl in sup_r50 mono_r18 mono_r50; do
-echo "$wl plain split / not | force-overlap split / not: $(one --workload $wl) $(one --workload $wl --opt tail_split=0) $(one --workload $wl) $(one --workload $wl --opt tail_split=0) | $(one --workload $wl --force-overlap) $(one --workload $wl --force-overlap --opt tail_split=0) $(one --workload $wl --force-overlap) $(one --workload $wl --force-overlap --opt tail_split=0)"
+echo "$wl plain / force-overlap: $(one --workload $wl) $(one --workload $wl --force-overlap) $(one --workload $wl) $(one --workload $wl --force-overlap)"
 done
 } > gpurun_out/r03ad_tail.txt 2>&1
 cat gpurun_out/r03ad_tail.txt
